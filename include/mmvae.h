@@ -1,0 +1,141 @@
+/* mmvae.h -- C ABI of the MI355X-native conv-VAE train path (libmmvae_hip.so).
+ *
+ * The reference (praateekmahajan/moving-mnist-vae) is pure Python and has no FFI of its own: the
+ * arithmetic of its hot path is reached through torch.nn / torch.optim.  This header is therefore the
+ * boundary a maintainer would bind (ctypes) in place of those calls.  Each entry point
+ * cites the reference lines whose arithmetic it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked "host"; nothing is allocated
+ *     or freed by the library except the opaque mmvae_net handle (host memory only);
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*), never synchronise, and are
+ *     hipGraph-capturable;
+ *   - return value: 0 (or a positive count where documented) on success, negative MMVAE_ERR_* on failure,
+ *     with a human-readable message from mmvae_last_error();
+ *   - dtype: 0 = f32 storage / exact-f32 MFMA, 1 = bf16 storage / bf16 MFMA with f32 accumulation.
+ *     Parameters, gradients, BN statistics, latents and the reconstruction are always f32.
+ *   - activation layout is NHWC; the network boundary (image in, reconstruction out) is NCHW like the
+ *     reference (identical for the 1-channel image).
+ */
+#ifndef MMVAE_H_
+#define MMVAE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MMVAE_API __attribute__((visibility("default")))
+#else
+#define MMVAE_API
+#endif
+
+#define MMVAE_OK 0
+#define MMVAE_ERR_ARG (-1)
+#define MMVAE_ERR_HIP (-2)
+#define MMVAE_ERR_WORKSPACE (-3)
+#define MMVAE_ERR_UNSUPPORTED (-4)
+
+#define MMVAE_F32 0
+#define MMVAE_BF16 1
+
+MMVAE_API int mmvae_abi_version(void);
+MMVAE_API const char* mmvae_last_error(void);          /* host string, valid until the next failing call on this thread */
+
+/* ------------------------------------------------------------------ network handle
+ * Describes VAE(in_channels, ., decoder_out_channels, ., z_dimension, pixelcnn=False, only_pixelcnn=False, ...,
+ * require_rsample, ., input_image_size)  -- model.py:258-310 (encoder :88-112, decoder :153-179).  */
+typedef struct mmvae_net mmvae_net;
+MMVAE_API int mmvae_net_create(mmvae_net** out, int in_channels, int z_dimension, int out_channels, int image_size,
+                     int need_logvar, int dtype);
+MMVAE_API void mmvae_net_destroy(mmvae_net* net);
+/* Flat storage sizes: f32 parameters, f32 BN running statistics, int64 num_batches_tracked counters; first
+ * decoder parameter (for gradient bucketing); decoder output side (32 or 64, model.py:169,191). */
+MMVAE_API int mmvae_net_sizes(const mmvae_net* net, int64_t* n_params, int64_t* n_bn_f32, int32_t* n_bn_i64,
+                    int64_t* decoder_param_offset, int32_t* decoder_side);
+/* state_dict inventory in the reference's registration order (183 entries at the default config).
+ * kind: 0 parameter (offset into the flat parameter buffer), 1 BN f32 buffer, 2 BN int64 counter. */
+MMVAE_API int mmvae_net_num_entries(const mmvae_net* net);
+MMVAE_API int mmvae_net_entry(const mmvae_net* net, int index, char* name, int name_cap, int32_t* ndim, int32_t shape[4],
+                    int32_t* kind, int64_t* offset);
+/* Bytes of activation workspace needed for a batch of N frames (forward + backward). */
+MMVAE_API size_t mmvae_net_workspace_bytes(mmvae_net* net, int N);
+
+/* VAE_Encoder.forward, model.py:114-130 (BasicBlock.forward :39-55).  x: [N,1,S,S] f32.  Writes mu, logvar
+ * [N,z] f32 (logvar may be NULL when need_logvar=0).  training!=0: batch statistics, running-stat update with
+ * momentum 0.1 / unbiased variance and num_batches_tracked += 1 (nn.BatchNorm2d); else running statistics. */
+MMVAE_API int mmvae_encoder_fwd(mmvae_net* net, int N, const float* x, const float* params, float* bn_f32, int64_t* bn_i64,
+                      void* workspace, size_t workspace_bytes, float* mu, float* logvar, int training, void* stream);
+/* autograd of the above (loss.backward(), main.py:398): accumulates (+=) parameter gradients into `grads`
+ * (same flat layout as params; caller zeroes).  No gradient is produced for the image. */
+MMVAE_API int mmvae_encoder_bwd(mmvae_net* net, int N, const float* d_mu, const float* d_logvar, const float* params, float* grads,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* VAE_Decoder.forward, model.py:181-194 (DeconvBottleneck.forward :70-85).  encoding: [N,z] f32.
+ * recon: [N,out_channels,Sd,Sd] f32 NCHW, Sd = decoder_side (crop by `adjust`, model.py:328-329, is the caller's view). */
+MMVAE_API int mmvae_decoder_fwd(mmvae_net* net, int N, const float* encoding, const float* params, float* bn_f32, int64_t* bn_i64,
+                      void* workspace, size_t workspace_bytes, float* recon, int training, void* stream);
+MMVAE_API int mmvae_decoder_bwd(mmvae_net* net, int N, const float* d_recon, const float* params, float* grads, void* workspace,
+                      size_t workspace_bytes, float* d_encoding /* may be NULL */, void* stream);
+
+/* ------------------------------------------------------------------ latent + loss (model.py:148-150, :364-406)
+ * Reparameterisation  enc = mu + eps * exp(0.5*logvar)  (VAE_Encoder.rsample, model.py:148-150). */
+MMVAE_API int mmvae_rsample_fwd(const float* mu, const float* logvar, const float* eps, float* enc, int64_t n, void* stream);
+MMVAE_API int mmvae_rsample_bwd(const float* d_enc, const float* logvar, const float* eps, float* d_mu, float* d_logvar, int64_t n,
+                      void* stream);
+/* acc[0] += -0.5*sum(logvar - exp(logvar) - mu^2 + 1)   (VAE.kl_divergence, model.py:364-365); acc is f64, caller-zeroed */
+MMVAE_API int mmvae_kl_fwd(const float* mu, const float* logvar, int64_t n, double* acc, void* stream);
+/* d_mu = c*mu ; d_logvar = c*0.5*(exp(logvar)-1), c = coef * (gscale ? gscale[0] : 1).  In every *_bwd below `gscale` is an
+ * optional DEVICE scalar (the upstream d(loss), so loss.backward() needs no host sync). */
+MMVAE_API int mmvae_kl_bwd(const float* mu, const float* logvar, float coef, const float* gscale, float* d_mu, float* d_logvar, int64_t n,
+                 void* stream);
+/* acc[0] += -sum log N(target; recon, sigma)   (model.py:403) */
+MMVAE_API int mmvae_gauss_nll_fwd(const float* recon, const float* target, int64_t n, float sigma, double* acc, void* stream);
+MMVAE_API int mmvae_gauss_nll_bwd(const float* recon, const float* target, int64_t n, float sigma, float coef, const float* gscale,
+                        float* d_recon, void* stream);
+/* acc[0] += sum w[t]*CE(recon[:, :, p], t)   (F.cross_entropy(reduction='none', weight).sum(), model.py:400-401);
+ * recon [N,Q,HW] f32, target [N,HW] int64, weight [Q] f32 or NULL */
+MMVAE_API int mmvae_ce_fwd(const float* recon, const int64_t* target, const float* weight, int N, int Q, int HW, double* acc, void* stream);
+MMVAE_API int mmvae_ce_bwd(const float* recon, const int64_t* target, const float* weight, int N, int Q, int HW, float coef,
+                 const float* gscale, float* d_recon, void* stream);
+/* acc[0] += sum k(x,x) + sum k(y,y) - 2 sum k(x,y),  k(a,b) = exp(-|a-b|^2 / d^2)   (compute_mmd, model.py:367-383);
+ * x = true_samples, y = encoding, both [n,d] f32.  Never materialises (n,n,d). */
+MMVAE_API int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, double* acc, void* stream);
+/* d_y += coef * d(mmd)/dy */
+MMVAE_API int mmvae_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, void* stream);
+/* acc = {px, kl, mmd} (f64) -> out[4] = {(nll*px + kl_coef*kl + mmd_coef*mmd)/n, nll*px/n, kl/n, mmd/n}  (model.py:405-406) */
+MMVAE_API int mmvae_loss_finish(const double* acc, float* out, float nll, float kl_coef, float mmd_coef, float n, void* stream);
+
+/* ------------------------------------------------------------------ train-step plumbing
+ * (label - mean)/std, main.py:383-387.  labels int64 [n]; image f32 [n]. */
+MMVAE_API int mmvae_normalise_labels(const int64_t* labels, int64_t n, float mean, float stdv, float* image, void* stream);
+/* torch.optim.Adam defaults (main.py:468) over a flat buffer: bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t);
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+MMVAE_API int mmvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ single ops (layer-level parity tests)
+ * Conv2d / ConvTranspose2d with PyTorch weight layouts on NHWC activations of `dtype`:
+ *   x [N,H,W,Cin], y [N,Ho,Wo,Cout];  weight f32 (Cout,Cin,k,k) for Conv2d, (Cin,Cout,k,k) for ConvTranspose2d.
+ * scratch: device buffer of at least 2*numel(weight)*sizeof(dtype)+64 bytes for the packed weights.
+ * pro_scale/pro_shift (per input channel, nullable): x := relu?(x*scale+shift) applied on load (fused BN+ReLU).
+ * stats (nullable): per-channel (sum,sumsq) partials [rows][2][Cout]; the call returns `rows`. */
+MMVAE_API int mmvae_conv2d_fwd(int dtype, int transposed, const void* x, const float* weight, void* y, int N, int H, int W, int Cin, int Cout,
+                     int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu, float* stats,
+                     void* scratch, void* stream);
+/* dx [N,H,W,Cin] from dy [N,Ho,Wo,Cout] */
+MMVAE_API int mmvae_conv2d_dgrad(int dtype, int transposed, const void* dy, const float* weight, void* dx, int N, int H, int W, int Cin,
+                       int Cout, int k, int stride, int pad, void* scratch, void* stream);
+/* dW (f32, weight layout) += ... ; pro_* as in fwd (applied to x) */
+MMVAE_API int mmvae_conv2d_wgrad(int dtype, int transposed, const void* x, const void* dy, float* dweight, int N, int H, int W, int Cin,
+                       int Cout, int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu,
+                       void* stream);
+/* f32 <-> dtype element conversion (n elements) */
+MMVAE_API int mmvae_convert(int dtype_in, int dtype_out, const void* in, void* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMVAE_H_ */

@@ -1,0 +1,83 @@
+"""ctypes binding of libmmvae_hip.so (the C ABI declared in include/mmvae.h).
+
+There is no CPU fallback: if the library is missing the product path raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
+_lib = None
+
+P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/mmvae.h one to one (checked by tests/test_capi_cpu.py)
+PROTOTYPES = {
+    "mmvae_abi_version": (c_int, []),
+    "mmvae_last_error": (c_char_p, []),
+    "mmvae_net_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mmvae_net_destroy": (None, [P]),
+    "mmvae_net_sizes": (c_int, [P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_int64), POINTER(c_int32)]),
+    "mmvae_net_num_entries": (c_int, [P]),
+    "mmvae_net_entry": (c_int, [P, c_int, c_char_p, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
+    "mmvae_net_workspace_bytes": (c_size_t, [P, c_int]),
+    "mmvae_encoder_fwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P, P, c_int, P]),
+    "mmvae_encoder_bwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P]),
+    "mmvae_decoder_fwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P, c_int, P]),
+    "mmvae_decoder_bwd": (c_int, [P, c_int, P, P, P, P, c_size_t, P, P]),
+    "mmvae_rsample_fwd": (c_int, [P, P, P, P, c_int64, P]),
+    "mmvae_rsample_bwd": (c_int, [P, P, P, P, P, c_int64, P]),
+    "mmvae_kl_fwd": (c_int, [P, P, c_int64, P, P]),
+    "mmvae_kl_bwd": (c_int, [P, P, c_float, P, P, P, c_int64, P]),
+    "mmvae_gauss_nll_fwd": (c_int, [P, P, c_int64, c_float, P, P]),
+    "mmvae_gauss_nll_bwd": (c_int, [P, P, c_int64, c_float, c_float, P, P, P]),
+    "mmvae_ce_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "mmvae_ce_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, P]),
+    "mmvae_mmd_fwd": (c_int, [P, P, c_int, c_int, P, P]),
+    "mmvae_mmd_bwd": (c_int, [P, P, c_int, c_int, c_float, P, P, P]),
+    "mmvae_loss_finish": (c_int, [P, P, c_float, c_float, c_float, c_float, P]),
+    "mmvae_normalise_labels": (c_int, [P, c_int64, c_float, c_float, P, P]),
+    "mmvae_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "mmvae_conv2d_fwd": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
+    "mmvae_conv2d_dgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "mmvae_conv2d_wgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "mmvae_convert": (c_int, [c_int, c_int, P, P, c_int64, P]),
+}
+
+
+class MmvaeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmvaeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C moving-mnist-vae_amd/csrc`). "
+            "There is no CPU fallback for the product path.")
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        msg = lib().mmvae_last_error()
+        raise MmvaeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+    return rc
+
+
+def ptr(t):
+    """Device/host pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,429 @@
+// Train-mode BatchNorm pieces and the residual joins, as bandwidth kernels (16-byte NHWC vectors).
+//
+// Forward BN-apply(+ReLU) is normally fused into the consumer conv's load prologue (conv_gemm.hip);
+// what is here: per-channel statistics, the finalize step (scale/shift, running stats), the two-input
+// residual join, and the backward reductions / dy materialisation  dy = A*g + B*y + C  per channel.
+#include "kernels.hpp"
+
+namespace mmvae {
+
+constexpr int kElemMaxBlocks = 2048;
+
+__host__ __device__ inline int block_threads_for(int cvecs) {
+  // a block size that is a multiple of cvecs, so a thread's channel group never changes in a grid-stride loop
+  int b = 256 - (256 % cvecs);
+  return b < cvecs ? cvecs : b;
+}
+
+static int elem_blocks(long nvec, int threads) {
+  long b = (nvec + (long)threads * 4 - 1) / ((long)threads * 4);
+  if (b < 1) b = 1;
+  if (b > kElemMaxBlocks) b = kElemMaxBlocks;
+  return (int)b;
+}
+
+// Per-thread channel-group partials -> per-block per-channel sums.  vals[NV][VE] per thread; threads with equal
+// (threadIdx.x % cvecs) share channels.  Writes out[v*C + cg*VE + j] for v<NV.
+template <int NV, int VE>
+__device__ __forceinline__ void block_channel_reduce(float (&vals)[NV][VE], int cvecs, int C, float* smem, float* out) {
+  // smem: blockDim.x * NV * VE floats
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int j = 0; j < VE; ++j) smem[(t * NV + v) * VE + j] = vals[v][j];
+  __syncthreads();
+  for (int o = t; o < cvecs * NV * VE; o += blockDim.x) {
+    const int cg = o / (NV * VE), rem = o - cg * (NV * VE);
+    float s = 0.f;
+    for (int tt = cg; tt < (int)blockDim.x; tt += cvecs) s += smem[tt * NV * VE + rem];
+    const int v = rem / VE, j = rem - v * VE;
+    out[(long)v * C + cg * VE + j] = s;
+  }
+}
+
+// ---------------------------------------------------------------- channel statistics (NHWC)
+template <typename T>
+__global__ void chan_stats_nhwc_kernel(const T* __restrict__ y, long nvec, int C, float* __restrict__ partials) {
+  constexpr int VE = Elem<T>::kVec;
+  extern __shared__ float smem[];
+  const int cvecs = C / VE;
+  float acc[2][VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    float f[VE];
+    Elem<T>::unpack(reinterpret_cast<const Vec16*>(y)[v], f);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { acc[0][j] += f[j]; acc[1][j] += f[j] * f[j]; }
+  }
+  block_channel_reduce<2, VE>(acc, cvecs, C, smem, partials + (long)blockIdx.x * 2 * C);
+}
+
+int chan_stats_parts(long, int) { return 1024; }   // upper bound on partial rows of every reduction kernel
+
+int launch_chan_stats_nhwc(int dt, const void* y, long npix, int C, float* partials, hipStream_t s) {
+  const int VE = dt == DT_F32 ? 4 : 8;
+  if (C % VE) { set_error("chan_stats: C=%d not a multiple of %d", C, VE); return MMVAE_ERR_UNSUPPORTED; }
+  const int cvecs = C / VE, threads = block_threads_for(cvecs);
+  const long nvec = npix * cvecs;
+  int blocks = elem_blocks(nvec, threads);
+  if (blocks > 1024) blocks = 1024;
+  const size_t sm = (size_t)threads * 2 * VE * sizeof(float);
+  if (dt == DT_F32) hipLaunchKernelGGL((chan_stats_nhwc_kernel<float>), dim3(blocks), dim3(threads), sm, s, (const float*)y, nvec, C, partials);
+  else hipLaunchKernelGGL((chan_stats_nhwc_kernel<bf16_t>), dim3(blocks), dim3(threads), sm, s, (const bf16_t*)y, nvec, C, partials);
+  int rc = check_launch("chan_stats_nhwc");
+  return rc ? rc : blocks;
+}
+
+// ---------------------------------------------------------------- channel statistics (NCHW f32)
+// planes = N*C; block handles planes blockIdx.x, +gridDim.x, ...; partials [gridDim.x][NR][C]
+template <int NR>
+__global__ void plane_reduce_nchw_kernel(const float* __restrict__ a, const float* __restrict__ b, int N, int C, int HW,
+                                         float* __restrict__ partials) {
+  // NR=2, b==null: (sum a, sum a^2);  NR=2, b!=null: (sum a, sum a*b)
+  extern __shared__ float sm[];
+  float* sAcc = sm;             // [NR][C]
+  float* sRed = sm + NR * C;    // [NR * nwaves]
+  for (int i = threadIdx.x; i < NR * C; i += blockDim.x) sAcc[i] = 0.f;
+  __syncthreads();
+  const int planes = N * C;
+  for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+    const int c = p % C;
+    const float* pa = a + (long)p * HW;
+    const float* pb = b ? b + (long)p * HW : nullptr;
+    float v[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+      const float x = pa[i];
+      v[0] += x;
+      v[1] += pb ? x * pb[i] : x * x;
+    }
+    block_sum<2>(v, sRed);
+    if (threadIdx.x == 0) { sAcc[c] += v[0]; sAcc[C + c] += v[1]; }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < NR * C; i += blockDim.x) partials[(long)blockIdx.x * NR * C + i] = sAcc[i];
+}
+
+static int nchw_parts(int N, int C) { int p = N * C; return p > 512 ? 512 : (p < 1 ? 1 : p); }
+
+int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials, hipStream_t s) {
+  const int blocks = nchw_parts(N, C);
+  const size_t sm = (2 * C + 2 * 4) * sizeof(float);
+  hipLaunchKernelGGL((plane_reduce_nchw_kernel<2>), dim3(blocks), dim3(256), sm, s, y, (const float*)nullptr, N, C, HW, partials);
+  int rc = check_launch("chan_stats_nchw");
+  return rc ? rc : blocks;
+}
+
+int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s) {
+  const int blocks = nchw_parts(N, C);
+  const size_t sm = (2 * C + 2 * 4) * sizeof(float);
+  hipLaunchKernelGGL((plane_reduce_nchw_kernel<2>), dim3(blocks), dim3(256), sm, s, dout, y, N, C, HW, partials);
+  int rc = check_launch("bn_bwd_reduce_nchw");
+  return rc ? rc : blocks;
+}
+
+// ---------------------------------------------------------------- finalize (training)
+__global__ void bn_finalize_kernel(BnFinalizeArgs a) {
+  __shared__ double sRed[2 * 4];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = threadIdx.x; p < a.nparts; p += blockDim.x) {
+    s1 += (double)a.partials[(long)p * 2 * a.C + c];
+    s2 += (double)a.partials[(long)p * 2 * a.C + a.C + c];
+  }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sRed[wid] = s1; sRed[4 + wid] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    s1 = 0.0; s2 = 0.0;
+    for (int w = 0; w < nw; ++w) { s1 += sRed[w]; s2 += sRed[4 + w]; }
+    const double n = a.count;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double istd = 1.0 / sqrt(var + (double)a.eps);
+    const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
+    a.mean[c] = (float)mean;
+    a.istd[c] = (float)istd;
+    const float sc = (float)((double)g * istd);
+    a.scale[c] = sc;
+    a.shift[c] = (float)((double)b - mean * (double)g * istd);
+    if (a.running_mean) {
+      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+      a.running_mean[c] = (float)((1.0 - (double)a.momentum) * (double)a.running_mean[c] + (double)a.momentum * mean);
+      a.running_var[c] = (float)((1.0 - (double)a.momentum) * (double)a.running_var[c] + (double)a.momentum * unbiased);
+    }
+    if (c == 0 && a.nbt) *a.nbt += 1;
+  }
+}
+
+int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(256), 0, s, a);
+  return check_launch("bn_finalize");
+}
+
+__global__ void bn_eval_affine_kernel(const float* g, const float* b, const float* rm, const float* rv, float eps, int C,
+                                      float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float istd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = g[c] * istd;
+    scale[c] = sc;
+    shift[c] = b[c] - rm[c] * sc;
+  }
+}
+int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                          float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, eps, C, scale, shift);
+  return check_launch("bn_eval_affine");
+}
+
+// ---------------------------------------------------------------- forward elementwise
+template <typename T, bool TWO>
+__global__ void affine_join_kernel(const T* __restrict__ a, const float* __restrict__ sa, const float* __restrict__ ba,
+                                   const T* __restrict__ b, const float* __restrict__ sb, const float* __restrict__ bb,
+                                   int relu, T* __restrict__ out, long nvec, int C) {
+  constexpr int VE = Elem<T>::kVec;
+  const int cvecs = C / VE;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const int cg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % cvecs);   // constant: blockDim % cvecs == 0
+  float s0[VE], b0[VE], s1[VE], b1[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    s0[j] = sa[cg * VE + j]; b0[j] = ba[cg * VE + j];
+    s1[j] = TWO ? sb[cg * VE + j] : 0.f; b1[j] = TWO ? bb[cg * VE + j] : 0.f;
+  }
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    float fa[VE], fb[VE];
+    Elem<T>::unpack(reinterpret_cast<const Vec16*>(a)[v], fa);
+    if (TWO) Elem<T>::unpack(reinterpret_cast<const Vec16*>(b)[v], fb);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      float x = fa[j] * s0[j] + b0[j];
+      if (TWO) x += fb[j] * s1[j] + b1[j];
+      fa[j] = relu ? fmaxf(x, 0.f) : x;
+    }
+    reinterpret_cast<Vec16*>(out)[v] = Elem<T>::pack(fa);
+  }
+}
+
+template <typename T>
+static int launch_affine_join_t(const void* a, const float* sa, const float* ba, const void* b, const float* sb, const float* bb,
+                                int relu, void* out, long npix, int C, hipStream_t s) {
+  constexpr int VE = Elem<T>::kVec;
+  if (C % VE) { set_error("affine/join: C=%d not a multiple of %d", C, VE); return MMVAE_ERR_UNSUPPORTED; }
+  const int cvecs = C / VE, threads = block_threads_for(cvecs);
+  const long nvec = npix * cvecs;
+  const int blocks = elem_blocks(nvec, threads);
+  if (b) hipLaunchKernelGGL((affine_join_kernel<T, true>), dim3(blocks), dim3(threads), 0, s, (const T*)a, sa, ba, (const T*)b, sb, bb, relu, (T*)out, nvec, C);
+  else hipLaunchKernelGGL((affine_join_kernel<T, false>), dim3(blocks), dim3(threads), 0, s, (const T*)a, sa, ba, (const T*)nullptr, sb, bb, relu, (T*)out, nvec, C);
+  return check_launch("affine_join");
+}
+
+int launch_join_fwd(int dt, const void* a, const float* sa, const float* ba, const void* b, const float* sb, const float* bb,
+                    void* out, long npix, int C, hipStream_t s) {
+  return dt == DT_F32 ? launch_affine_join_t<float>(a, sa, ba, b, sb, bb, 1, out, npix, C, s)
+                      : launch_affine_join_t<bf16_t>(a, sa, ba, b, sb, bb, 1, out, npix, C, s);
+}
+int launch_affine_act(int dt, const void* a, const float* sa, const float* ba, int relu, void* out, long npix, int C, hipStream_t s) {
+  return dt == DT_F32 ? launch_affine_join_t<float>(a, sa, ba, nullptr, nullptr, nullptr, relu, out, npix, C, s)
+                      : launch_affine_join_t<bf16_t>(a, sa, ba, nullptr, nullptr, nullptr, relu, out, npix, C, s);
+}
+
+// ---------------------------------------------------------------- backward reductions
+// MODE 0: mask from out>0 ; MODE 1: mask from y0*ms+mb>0 ; MODE 2: no mask
+template <typename T, int NY, int MODE>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out, const float* __restrict__ ms,
+                                     const float* __restrict__ mb, const T* __restrict__ y0, const T* __restrict__ y1,
+                                     long nvec, int C, float* __restrict__ partials) {
+  constexpr int VE = Elem<T>::kVec;
+  extern __shared__ float smem[];
+  const int cvecs = C / VE;
+  const int cg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % cvecs);
+  float msc[VE], msh[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) { msc[j] = MODE == 1 ? ms[cg * VE + j] : 0.f; msh[j] = MODE == 1 ? mb[cg * VE + j] : 0.f; }
+  float acc[1 + NY][VE];
+#pragma unroll
+  for (int q = 0; q < 1 + NY; ++q)
+#pragma unroll
+    for (int j = 0; j < VE; ++j) acc[q][j] = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    float g[VE], o[VE], a0[VE], a1[VE];
+    Elem<T>::unpack(reinterpret_cast<const Vec16*>(dout)[v], g);
+    Elem<T>::unpack(reinterpret_cast<const Vec16*>(y0)[v], a0);
+    if (MODE == 0) Elem<T>::unpack(reinterpret_cast<const Vec16*>(out)[v], o);
+    if (NY == 2) Elem<T>::unpack(reinterpret_cast<const Vec16*>(y1)[v], a1);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      bool on = true;
+      if (MODE == 0) on = o[j] > 0.f;
+      if (MODE == 1) on = (a0[j] * msc[j] + msh[j]) > 0.f;
+      const float gg = on ? g[j] : 0.f;
+      acc[0][j] += gg;
+      acc[1][j] += gg * a0[j];
+      if (NY == 2) acc[2][j] += gg * a1[j];
+    }
+  }
+  block_channel_reduce<1 + NY, VE>(acc, cvecs, C, smem, partials + (long)blockIdx.x * (1 + NY) * C);
+}
+
+template <typename T>
+static int launch_bn_bwd_reduce_t(const void* dout, const void* out, const float* ms, const float* mb, const void* y0,
+                                  const void* y1, long npix, int C, float* partials, hipStream_t s) {
+  constexpr int VE = Elem<T>::kVec;
+  if (C % VE) { set_error("bn_bwd_reduce: C=%d not a multiple of %d", C, VE); return MMVAE_ERR_UNSUPPORTED; }
+  const int cvecs = C / VE, threads = block_threads_for(cvecs);
+  const long nvec = npix * cvecs;
+  int blocks = elem_blocks(nvec, threads);
+  if (blocks > 1024) blocks = 1024;
+  const int ny = y1 ? 2 : 1;
+  const size_t sm = (size_t)threads * (1 + ny) * VE * sizeof(float);
+  const int mode = out ? 0 : (ms ? 1 : 2);
+#define MMVAE_LAUNCH(NY, MODE) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, NY, MODE>), dim3(blocks), dim3(threads), sm, s, \
+    (const T*)dout, (const T*)out, ms, mb, (const T*)y0, (const T*)y1, nvec, C, partials)
+  if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else MMVAE_LAUNCH(2, 2); }
+  else { if (mode == 0) MMVAE_LAUNCH(1, 0); else if (mode == 1) MMVAE_LAUNCH(1, 1); else MMVAE_LAUNCH(1, 2); }
+#undef MMVAE_LAUNCH
+  int rc = check_launch("bn_bwd_reduce");
+  return rc ? rc : blocks;
+}
+int launch_bn_bwd_reduce(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
+                         const void* y0, const void* y1, long npix, int C, float* partials, hipStream_t s) {
+  return dt == DT_F32 ? launch_bn_bwd_reduce_t<float>(dout, out, msk_scale, msk_shift, y0, y1, npix, C, partials, s)
+                      : launch_bn_bwd_reduce_t<bf16_t>(dout, out, msk_scale, msk_shift, y0, y1, npix, C, partials, s);
+}
+
+__global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
+  __shared__ double sRed[2 * 4];
+  const int c = blockIdx.x;
+  const int rows = 1 + a.ny;
+  double s0 = 0.0, s1 = 0.0;
+  for (int p = threadIdx.x; p < a.nparts; p += blockDim.x) {
+    s0 += (double)a.partials[((long)p * rows) * a.C + c];
+    s1 += (double)a.partials[((long)p * rows + 1 + a.which) * a.C + c];
+  }
+  s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { sRed[wid] = s0; sRed[4 + wid] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    s0 = 0.0; s1 = 0.0;
+    for (int w = 0; w < nw; ++w) { s0 += sRed[w]; s1 += sRed[4 + w]; }
+    const double mean = a.mean[c], istd = a.istd[c], g = a.gamma ? a.gamma[c] : 1.0;
+    const double sgy = istd * (s1 - mean * s0);       // sum g * yhat
+    if (a.dgamma) a.dgamma[c] += (float)sgy;
+    if (a.dbeta) a.dbeta[c] += (float)s0;
+    const double m1 = s0 / a.count, m2 = sgy / a.count;
+    const double A = g * istd;
+    a.coefA[c] = (float)A;
+    a.coefB[c] = (float)(-A * m2 * istd);
+    a.coefC[c] = (float)(-A * m1 + A * m2 * istd * mean);
+  }
+}
+int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(256), 0, s, a);
+  return check_launch("bn_bwd_finalize");
+}
+
+template <typename T, int NY, int MODE>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const float* __restrict__ ms,
+                                    const float* __restrict__ mb, const T* __restrict__ y0, const float* __restrict__ A0,
+                                    const float* __restrict__ B0, const float* __restrict__ C0, T* __restrict__ dy0,
+                                    const T* __restrict__ y1, const float* __restrict__ A1, const float* __restrict__ B1,
+                                    const float* __restrict__ C1, T* __restrict__ dy1, long nvec, int C) {
+  constexpr int VE = Elem<T>::kVec;
+  const int cvecs = C / VE;
+  const int cg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % cvecs);
+  float msc[VE], msh[VE], a0[VE], b0[VE], c0[VE], a1[VE], b1[VE], c1[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    const int ch = cg * VE + j;
+    msc[j] = MODE == 1 ? ms[ch] : 0.f; msh[j] = MODE == 1 ? mb[ch] : 0.f;
+    a0[j] = A0[ch]; b0[j] = B0[ch]; c0[j] = C0[ch];
+    a1[j] = NY == 2 ? A1[ch] : 0.f; b1[j] = NY == 2 ? B1[ch] : 0.f; c1[j] = NY == 2 ? C1[ch] : 0.f;
+  }
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+    float g[VE], o[VE], f0[VE], f1[VE], r0[VE], r1[VE];
+    Elem<T>::unpack(reinterpret_cast<const Vec16*>(dout)[v], g);
+    Elem<T>::unpack(reinterpret_cast<const Vec16*>(y0)[v], f0);
+    if (MODE == 0) Elem<T>::unpack(reinterpret_cast<const Vec16*>(out)[v], o);
+    if (NY == 2) Elem<T>::unpack(reinterpret_cast<const Vec16*>(y1)[v], f1);
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      bool on = true;
+      if (MODE == 0) on = o[j] > 0.f;
+      if (MODE == 1) on = (f0[j] * msc[j] + msh[j]) > 0.f;
+      const float gg = on ? g[j] : 0.f;
+      r0[j] = a0[j] * gg + b0[j] * f0[j] + c0[j];
+      if (NY == 2) r1[j] = a1[j] * gg + b1[j] * f1[j] + c1[j];
+    }
+    reinterpret_cast<Vec16*>(dy0)[v] = Elem<T>::pack(r0);
+    if (NY == 2) reinterpret_cast<Vec16*>(dy1)[v] = Elem<T>::pack(r1);
+  }
+}
+
+template <typename T>
+static int launch_bn_bwd_apply_t(const void* dout, const void* out, const float* ms, const float* mb, const void* y0,
+                                 const float* A0, const float* B0, const float* C0, void* dy0, const void* y1, const float* A1,
+                                 const float* B1, const float* C1, void* dy1, long npix, int C, hipStream_t s) {
+  constexpr int VE = Elem<T>::kVec;
+  if (C % VE) { set_error("bn_bwd_apply: C=%d not a multiple of %d", C, VE); return MMVAE_ERR_UNSUPPORTED; }
+  const int cvecs = C / VE, threads = block_threads_for(cvecs);
+  const long nvec = npix * cvecs;
+  const int blocks = elem_blocks(nvec, threads);
+  const int ny = y1 ? 2 : 1;
+  const int mode = out ? 0 : (ms ? 1 : 2);
+#define MMVAE_LAUNCH(NY, MODE) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, NY, MODE>), dim3(blocks), dim3(threads), 0, s, \
+    (const T*)dout, (const T*)out, ms, mb, (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, nvec, C)
+  if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else MMVAE_LAUNCH(2, 2); }
+  else { if (mode == 0) MMVAE_LAUNCH(1, 0); else if (mode == 1) MMVAE_LAUNCH(1, 1); else MMVAE_LAUNCH(1, 2); }
+#undef MMVAE_LAUNCH
+  return check_launch("bn_bwd_apply");
+}
+int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
+                        const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
+                        const void* y1, const float* A1, const float* B1, const float* C1, void* dy1,
+                        long npix, int C, hipStream_t s) {
+  return dt == DT_F32 ? launch_bn_bwd_apply_t<float>(dout, out, msk_scale, msk_shift, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, npix, C, s)
+                      : launch_bn_bwd_apply_t<bf16_t>(dout, out, msk_scale, msk_shift, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, npix, C, s);
+}
+
+// ---------------------------------------------------------------- NCHW f32 elementwise (output BN)
+__global__ void affine_nchw_kernel(const float* __restrict__ raw, const float* __restrict__ scale, const float* __restrict__ shift,
+                                   float* __restrict__ out, long total, int C, int HW) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    out[i] = raw[i] * scale[c] + shift[c];
+  }
+}
+int launch_affine_nchw(const float* raw, const float* scale, const float* shift, float* out, int N, int C, int HW, hipStream_t s) {
+  const long total = (long)N * C * HW;
+  const int blocks = elem_blocks(total / 4 + 1, 256);
+  hipLaunchKernelGGL(affine_nchw_kernel, dim3(blocks), dim3(256), 0, s, raw, scale, shift, out, total, C, HW);
+  return check_launch("affine_nchw");
+}
+__global__ void bn_bwd_apply_nchw_kernel(const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ A,
+                                         const float* __restrict__ B, const float* __restrict__ Cc, float* __restrict__ dy,
+                                         long total, int C, int HW) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    dy[i] = A[c] * dout[i] + B[c] * y[i] + Cc[c];
+  }
+}
+int launch_bn_bwd_apply_nchw(const float* dout, const float* y, const float* A, const float* B, const float* Cc, float* dy,
+                             int N, int C, int HW, hipStream_t s) {
+  const long total = (long)N * C * HW;
+  const int blocks = elem_blocks(total / 4 + 1, 256);
+  hipLaunchKernelGGL(bn_bwd_apply_nchw_kernel, dim3(blocks), dim3(256), 0, s, dout, y, A, B, Cc, dy, total, C, HW);
+  return check_launch("bn_bwd_apply_nchw");
+}
+
+}  // namespace mmvae

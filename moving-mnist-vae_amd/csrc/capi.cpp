@@ -1,0 +1,169 @@
+// extern "C" surface declared in include/mmvae.h.
+#include <cstring>
+#include <new>
+
+#include "../../include/mmvae.h"
+#include "conv_ops.hpp"
+#include "vae_net.hpp"
+
+namespace mmvae { const char* last_error(); }
+using namespace mmvae;
+
+struct mmvae_net { Net* net; };
+
+static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int mmvae_abi_version(void) { return 1; }
+const char* mmvae_last_error(void) { return last_error(); }
+
+int mmvae_net_create(mmvae_net** out, int in_channels, int z, int out_channels, int image_size, int need_logvar, int dtype) {
+  if (!out) return MMVAE_ERR_ARG;
+  if (in_channels != 1) { set_error("in_channels=%d unsupported (the hot path is the 1-channel Moving-MNIST VAE)", in_channels); return MMVAE_ERR_UNSUPPORTED; }
+  if (z <= 0 || z % 8) { set_error("z_dimension=%d must be a positive multiple of 8", z); return MMVAE_ERR_UNSUPPORTED; }
+  if (!(out_channels == 1 || out_channels == 2 || out_channels == 3 || out_channels == 4 || out_channels == 8)) {
+    set_error("decoder_out_channels=%d unsupported (1,2,3,4,8)", out_channels); return MMVAE_ERR_UNSUPPORTED; }
+  if (image_size < 9 || image_size > 64) { set_error("input_image_size=%d unsupported (9..64)", image_size); return MMVAE_ERR_UNSUPPORTED; }
+  if (dtype != MMVAE_F32 && dtype != MMVAE_BF16) { set_error("dtype=%d unsupported", dtype); return MMVAE_ERR_ARG; }
+  NetCfg c{in_channels, z, out_channels, image_size, need_logvar ? 1 : 0, dtype};
+  mmvae_net* h = new (std::nothrow) mmvae_net;
+  if (!h) return MMVAE_ERR_ARG;
+  h->net = new (std::nothrow) Net(c);
+  if (!h->net) { delete h; return MMVAE_ERR_ARG; }
+  *out = h;
+  return MMVAE_OK;
+}
+void mmvae_net_destroy(mmvae_net* n) { if (n) { delete n->net; delete n; } }
+
+int mmvae_net_sizes(const mmvae_net* n, int64_t* n_params, int64_t* n_bn_f32, int32_t* n_bn_i64, int64_t* dec_off, int32_t* dec_side) {
+  if (!n) return MMVAE_ERR_ARG;
+  if (n_params) *n_params = n->net->n_params;
+  if (n_bn_f32) *n_bn_f32 = n->net->n_bnbuf;
+  if (n_bn_i64) *n_bn_i64 = n->net->n_nbt;
+  if (dec_off) *dec_off = n->net->dec_param_off;
+  if (dec_side) *dec_side = n->net->Sd;
+  return MMVAE_OK;
+}
+int mmvae_net_num_entries(const mmvae_net* n) { return n ? (int)n->net->entries.size() : MMVAE_ERR_ARG; }
+int mmvae_net_entry(const mmvae_net* n, int i, char* name, int cap, int32_t* ndim, int32_t shape[4], int32_t* kind, int64_t* offset) {
+  if (!n || i < 0 || i >= (int)n->net->entries.size()) return MMVAE_ERR_ARG;
+  const Entry& e = n->net->entries[i];
+  if (name && cap > 0) { std::strncpy(name, e.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (ndim) *ndim = e.ndim;
+  if (shape) for (int k = 0; k < 4; ++k) shape[k] = e.shape[k];
+  if (kind) *kind = e.kind;
+  if (offset) *offset = e.offset;
+  return MMVAE_OK;
+}
+size_t mmvae_net_workspace_bytes(mmvae_net* n, int N) { return n && N > 0 ? n->net->workspace_bytes(N) : 0; }
+
+int mmvae_encoder_fwd(mmvae_net* n, int N, const float* x, const float* params, float* bn_f32, int64_t* bn_i64, void* ws, size_t wsb,
+                      float* mu, float* logvar, int training, void* stream) {
+  if (!n || N <= 0 || !x || !params || !ws || !mu) { set_error("encoder_fwd: bad argument"); return MMVAE_ERR_ARG; }
+  if (n->net->cfg.need_logvar && !logvar) { set_error("encoder_fwd: logvar required"); return MMVAE_ERR_ARG; }
+  if (!bn_f32) { set_error("encoder_fwd: BN buffers required"); return MMVAE_ERR_ARG; }
+  return n->net->encoder_fwd(N, x, params, bn_f32, reinterpret_cast<long long*>(bn_i64), ws, wsb, mu, logvar, training, S(stream));
+}
+int mmvae_encoder_bwd(mmvae_net* n, int N, const float* d_mu, const float* d_logvar, const float* params, float* grads, void* ws,
+                      size_t wsb, void* stream) {
+  if (!n || N <= 0 || !d_mu || !params || !grads || !ws) { set_error("encoder_bwd: bad argument"); return MMVAE_ERR_ARG; }
+  if (n->net->cfg.need_logvar && !d_logvar) { set_error("encoder_bwd: d_logvar required"); return MMVAE_ERR_ARG; }
+  return n->net->encoder_bwd(N, d_mu, d_logvar, params, grads, ws, wsb, S(stream));
+}
+int mmvae_decoder_fwd(mmvae_net* n, int N, const float* enc, const float* params, float* bn_f32, int64_t* bn_i64, void* ws, size_t wsb,
+                      float* recon, int training, void* stream) {
+  if (!n || N <= 0 || !enc || !params || !ws || !recon || !bn_f32) { set_error("decoder_fwd: bad argument"); return MMVAE_ERR_ARG; }
+  return n->net->decoder_fwd(N, enc, params, bn_f32, reinterpret_cast<long long*>(bn_i64), ws, wsb, recon, training, S(stream));
+}
+int mmvae_decoder_bwd(mmvae_net* n, int N, const float* d_recon, const float* params, float* grads, void* ws, size_t wsb, float* d_enc,
+                      void* stream) {
+  if (!n || N <= 0 || !d_recon || !params || !grads || !ws) { set_error("decoder_bwd: bad argument"); return MMVAE_ERR_ARG; }
+  return n->net->decoder_bwd(N, d_recon, params, grads, ws, wsb, d_enc, S(stream));
+}
+
+// ---- latent / loss
+int mmvae_rsample_fwd(const float* mu, const float* lv, const float* eps, float* enc, int64_t n, void* st) {
+  return launch_rsample_fwd(DT_F32, mu, lv, eps, enc, nullptr, (long)n, S(st));
+}
+int mmvae_rsample_bwd(const float* d_enc, const float* lv, const float* eps, float* d_mu, float* d_lv, int64_t n, void* st) {
+  return launch_rsample_bwd(d_enc, lv, eps, d_mu, d_lv, (long)n, S(st));
+}
+int mmvae_kl_fwd(const float* mu, const float* lv, int64_t n, double* acc, void* st) { return launch_kl_fwd(mu, lv, (long)n, acc, S(st)); }
+int mmvae_kl_bwd(const float* mu, const float* lv, float coef, const float* gscale, float* d_mu, float* d_lv, int64_t n, void* st) {
+  return launch_kl_bwd(mu, lv, coef, gscale, d_mu, d_lv, (long)n, S(st));
+}
+int mmvae_gauss_nll_fwd(const float* r, const float* t, int64_t n, float sigma, double* acc, void* st) {
+  if (!(sigma > 0.f)) { set_error("gauss_nll: sigma must be > 0"); return MMVAE_ERR_ARG; }
+  return launch_gauss_nll_fwd(r, t, (long)n, sigma, acc, S(st));
+}
+int mmvae_gauss_nll_bwd(const float* r, const float* t, int64_t n, float sigma, float coef, const float* gscale, float* d_r, void* st) {
+  if (!(sigma > 0.f)) { set_error("gauss_nll: sigma must be > 0"); return MMVAE_ERR_ARG; }
+  return launch_gauss_nll_bwd(r, t, (long)n, sigma, coef, gscale, d_r, S(st));
+}
+int mmvae_ce_fwd(const float* r, const int64_t* t, const float* w, int N, int Q, int HW, double* acc, void* st) {
+  return launch_ce_fwd(r, reinterpret_cast<const long long*>(t), w, N, Q, HW, acc, S(st));
+}
+int mmvae_ce_bwd(const float* r, const int64_t* t, const float* w, int N, int Q, int HW, float coef, const float* gscale, float* d_r,
+                 void* st) {
+  return launch_ce_bwd(r, reinterpret_cast<const long long*>(t), w, N, Q, HW, coef, gscale, d_r, S(st));
+}
+int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, double* acc, void* st) { return launch_mmd_fwd(x, y, n, d, acc, S(st)); }
+int mmvae_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, void* st) {
+  return launch_mmd_bwd(x, y, n, d, coef, gscale, d_y, S(st));
+}
+int mmvae_loss_finish(const double* acc, float* out, float nll, float kl_coef, float mmd_coef, float n, void* st) {
+  return launch_loss_finish(acc, out, nll, kl_coef, mmd_coef, n, S(st));
+}
+
+// ---- plumbing
+int mmvae_normalise_labels(const int64_t* labels, int64_t n, float mean, float stdv, float* image, void* st) {
+  return launch_normalise(DT_F32, reinterpret_cast<const long long*>(labels), (long)n, mean, stdv, nullptr, image, S(st));
+}
+int mmvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
+                    float bc2_sqrt, float grad_scale, void* st) {
+  AdamArgs a{p, g, m, v, (long)n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, grad_scale};
+  return launch_adam(a, S(st));
+}
+
+// ---- single ops
+static inline ConvGeom geom_for(int transposed, int Cin, int Cout, int k, int s, int p) {
+  // Conv2d weight (Cout,Cin,k,k): D0=Cout (small side = y), D1=Cin.  ConvT weight (Cin,Cout,k,k): D0=Cin (small side = x), D1=Cout.
+  return transposed ? ConvGeom{Cin, Cout, k, s, p} : ConvGeom{Cout, Cin, k, s, p};
+}
+static inline long numel_w(int Cin, int Cout, int k) { return (long)Cin * Cout * k * k; }
+static inline int out_size(int transposed, int H, int k, int s, int p) { return transposed ? (H - 1) * s - 2 * p + k : conv_down_size(H, k, s, p); }
+
+int mmvae_conv2d_fwd(int dt, int transposed, const void* x, const float* w, void* y, int N, int H, int W, int Cin, int Cout, int k,
+                     int s, int p, const float* ps, const float* pb, int relu, float* stats, void* scratch, void* st) {
+  const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
+  const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
+  if (!transposed) {
+    int rc = op_pack_down(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
+    return op_run_down(dt, dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st));
+  }
+  int rc = op_pack_up(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
+  return op_run_up(dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st));
+}
+int mmvae_conv2d_dgrad(int dt, int transposed, const void* dy, const float* w, void* dx, int N, int H, int W, int Cin, int Cout, int k,
+                       int s, int p, void* scratch, void* st) {
+  const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
+  const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
+  if (!transposed) {
+    int rc = op_pack_up(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
+    return op_run_up(dt, g, scratch, N, dy, Ho, Wo, dx, H, W, nullptr, nullptr, 0, nullptr, 0, S(st));
+  }
+  int rc = op_pack_down(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
+  return op_run_down(dt, dt, g, scratch, N, dy, Ho, Wo, dx, H, W, nullptr, nullptr, 0, nullptr, 0, S(st));
+}
+int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int k,
+                       int s, int p, const float* ps, const float* pb, int relu, void* st) {
+  const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
+  const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
+  (void)numel_w;
+  if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st));
+  return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st));
+}
+int mmvae_convert(int di, int dout, const void* in, void* out, int64_t n, void* st) { return launch_convert(di, dout, in, out, (long)n, S(st)); }
+
+}  // extern "C"

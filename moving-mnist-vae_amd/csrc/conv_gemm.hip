@@ -1,0 +1,486 @@
+// Implicit-GEMM convolution kernels on CDNA4 matrix cores (gfx950).
+//
+//  * gather_gemm_kernel : Conv2d forward, ConvTranspose2d forward and every data-gradient,
+//    as ONE gather-form GEMM  D[cout][pixel] = W[cout][k] * X[k][pixel]  (k = tap x cin).
+//    MFMA orientation is "weights x pixels" so each lane ends up with 4 consecutive output
+//    channels of one pixel -> 8/16-byte NHWC stores.
+//  * wgrad_kernel : weight gradients, D[a][b] = sum_pixels P[pixel][a] * G[pixel + tap][b].
+//
+// Both stage 128-byte K-rows (8 x 16-byte "kvecs") through LDS with an XOR swizzle and feed
+// v_mfma_f32_16x16x32_bf16 (bf16 storage) or v_mfma_f32_16x16x4_f32 (exact f32 mode).
+#include "kernels.hpp"
+
+namespace mmvae {
+
+constexpr int KV = 8;  // kvecs (16 B) per LDS row
+
+__device__ __forceinline__ int lds_slot(int row, int kv) { return row * KV + (kv ^ ((row >> 1) & 7)); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ f32x4 run(const Vec16& a, const Vec16& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // lane group g = lane>>4 holds k = 4g..4g+3 of a 16-wide chunk in BOTH operands; the four
+  // 16x16x4 MFMAs consume element j of every group, so the k-permutation cancels.
+  __device__ static __forceinline__ f32x4 run(const Vec16& a, const Vec16& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w[j]), __uint_as_float(b.w[j]), c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename TO> __device__ __forceinline__ void store4(TO* p, const float* v, bool acc);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v, bool acc) {
+  float4 o = make_float4(v[0], v[1], v[2], v[3]);
+  if (acc) { float4 e = *reinterpret_cast<const float4*>(p); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+  *reinterpret_cast<float4*>(p) = o;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v, bool acc) {
+  float f[4] = {v[0], v[1], v[2], v[3]};
+  if (acc) {
+    uint2 e = *reinterpret_cast<const uint2*>(p);
+    f[0] += __uint_as_float(e.x << 16); f[1] += __uint_as_float(e.x & 0xffff0000u);
+    f[2] += __uint_as_float(e.y << 16); f[3] += __uint_as_float(e.y & 0xffff0000u);
+  }
+  uint2 o;
+  o.x = (uint32_t)f32_to_bf16_bits(f[0]) | ((uint32_t)f32_to_bf16_bits(f[1]) << 16);
+  o.y = (uint32_t)f32_to_bf16_bits(f[2]) | ((uint32_t)f32_to_bf16_bits(f[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = o;
+}
+
+// ============================================================================ gather GEMM
+template <typename T, typename TO, int CT16>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(GatherArgs a) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int PT = 128;
+  constexpr int CT = CT16 * 16;
+  __shared__ Vec16 sX[PT * KV];
+  __shared__ Vec16 sW[CT * KV];
+  __shared__ float sPro[2 * 512];
+  __shared__ int sTap[2 * kMaxTaps];
+  __shared__ float sStat[4 * 2 * CT];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4, r = lane & 15;
+  const int cbase = blockIdx.y * CT;
+  const Phase P = a.phases[blockIdx.z];
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ Wt = reinterpret_cast<const T*>(a.w) + P.w_off;
+  TO* __restrict__ Y = reinterpret_cast<TO*>(a.y);
+  const bool has_pro = a.pro_scale != nullptr;
+  if (has_pro) {
+    for (int i = t; i < a.Cin; i += 256) { sPro[i] = a.pro_scale[i]; sPro[512 + i] = a.pro_shift[i]; }
+  }
+  if (t < P.ntaps) { sTap[2 * t] = a.taps[P.tap0 + t].dh; sTap[2 * t + 1] = a.taps[P.tap0 + t].dw; }
+  __syncthreads();
+
+  const int kvecs = P.ntaps * a.cin_vecs;
+  const int Ktot = kvecs * VE;
+  const int nks = (kvecs + KV - 1) / KV;
+  const int HqWq = P.Hq * P.Wq;
+  const int M = a.N * HqWq;
+  const int ntiles = (M + PT - 1) / PT;
+  const int kv_l = t & 7;           // this thread's kvec column in every K-step
+  const int row_l = t >> 3;         // rows row_l + 32*i
+
+  float st1[CT16][4], st2[CT16][4];
+#pragma unroll
+  for (int c = 0; c < CT16; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st1[c][j] = 0.f; st2[c][j] = 0.f; }
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- per-thread pixel decode for the 4 rows this thread stages
+    int pbase[4], ph0[4], pw0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = tile * PT + row_l + 32 * i;
+      if (m < M) {
+        const int n = m / HqWq, rem = m - n * HqWq;
+        const int hq = rem / P.Wq, wq = rem - hq * P.Wq;
+        pbase[i] = n * a.Hi * a.Wi;
+        ph0[i] = hq * a.SI;
+        pw0[i] = wq * a.SI;
+      } else {
+        pbase[i] = -1; ph0[i] = 0; pw0[i] = 0;
+      }
+    }
+    f32x4 acc[CT16][2];
+#pragma unroll
+    for (int c = 0; c < CT16; ++c) { acc[c][0] = (f32x4){0, 0, 0, 0}; acc[c][1] = (f32x4){0, 0, 0, 0}; }
+
+    for (int ks = 0; ks < nks; ++ks) {
+      // ---- stage X (gathered, optional affine+relu prologue, zero padding afterwards)
+      const int gk = ks * KV + kv_l;
+      int dh = 0, dw = 0, c0 = 0;
+      const bool kvalid = gk < kvecs;
+      if (kvalid) {
+        const int tap = gk / a.cin_vecs;
+        c0 = (gk - tap * a.cin_vecs) * VE;
+        dh = sTap[2 * tap]; dw = sTap[2 * tap + 1];
+      }
+      Vec16 xv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int hi = ph0[i] + dh, wi = pw0[i] + dw;
+        const bool ok = kvalid && pbase[i] >= 0 && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi;
+        if (ok) {
+          xv[i] = *reinterpret_cast<const Vec16*>(X + ((long)(pbase[i] + hi * a.Wi + wi) * a.Cin + c0));
+          if (has_pro) {
+            float f[VE];
+            Elem<T>::unpack(xv[i], f);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+              float v = f[j] * sPro[c0 + j] + sPro[512 + c0 + j];
+              f[j] = a.pro_relu ? fmaxf(v, 0.f) : v;
+            }
+            xv[i] = Elem<T>::pack(f);
+          }
+        } else {
+          xv[i] = Vec16{{0, 0, 0, 0}};
+        }
+      }
+      // ---- stage W
+      Vec16 wvv[(CT * KV + 255) / 256];
+#pragma unroll
+      for (int i = 0; i < (CT * KV + 255) / 256; ++i) {
+        const int v = t + 256 * i;
+        const int wr = v >> 3;
+        const bool ok = (v < CT * KV) && kvalid && (cbase + wr) < a.Cout;
+        wvv[i] = ok ? *reinterpret_cast<const Vec16*>(Wt + ((long)(cbase + wr) * Ktot + (long)gk * VE)) : Vec16{{0, 0, 0, 0}};
+      }
+      __syncthreads();   // previous K-step's fragment reads are done
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sX[lds_slot(row_l + 32 * i, kv_l)] = xv[i];
+#pragma unroll
+      for (int i = 0; i < (CT * KV + 255) / 256; ++i) {
+        const int v = t + 256 * i;
+        if (v < CT * KV) sW[lds_slot(v >> 3, kv_l)] = wvv[i];
+      }
+      __syncthreads();
+      // ---- MFMA
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int kvs = 4 * k2 + g;
+        const Vec16 b0 = sX[lds_slot(32 * wv + r, kvs)];
+        const Vec16 b1 = sX[lds_slot(32 * wv + 16 + r, kvs)];
+#pragma unroll
+        for (int c = 0; c < CT16; ++c) {
+          const Vec16 af = sW[lds_slot(16 * c + r, kvs)];
+          acc[c][0] = Mma<T>::run(af, b0, acc[c][0]);
+          acc[c][1] = Mma<T>::run(af, b1, acc[c][1]);
+        }
+      }
+    }
+    // ---- epilogue: lane holds couts (16c + 4g + j), pixel (32wv + 16pt + r)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int m = tile * PT + 32 * wv + 16 * pt + r;
+      if (m < M) {
+        const int n = m / HqWq, rem = m - n * HqWq;
+        const int hq = rem / P.Wq, wq = rem - hq * P.Wq;
+        const long obase = ((long)(n * a.Ho + hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw)) * a.Cout;
+#pragma unroll
+        for (int c = 0; c < CT16; ++c) {
+          const int co = cbase + 16 * c + 4 * g;
+          if (co < a.Cout) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = acc[c][pt][j] + (a.bias ? a.bias[co + j] : 0.f);
+              st1[c][j] += v[j];
+              st2[c][j] += v[j] * v[j];
+            }
+            store4<TO>(Y + obase + co, v, a.accumulate != 0);
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    // reduce over the 16 pixel-lanes that share g, then over the 4 waves
+#pragma unroll
+    for (int c = 0; c < CT16; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          st1[c][j] += __shfl_xor(st1[c][j], o, 64);
+          st2[c][j] += __shfl_xor(st2[c][j], o, 64);
+        }
+      }
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+      for (int c = 0; c < CT16; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sStat[wv * 2 * CT + 16 * c + 4 * g + j] = st1[c][j];
+          sStat[wv * 2 * CT + CT + 16 * c + 4 * g + j] = st2[c][j];
+        }
+    }
+    __syncthreads();
+    if (t < 2 * CT) {
+      const float s = sStat[t] + sStat[2 * CT + t] + sStat[4 * CT + t] + sStat[6 * CT + t];
+      const int which = t / CT, cl = t - which * CT;
+      if (cbase + cl < a.Cout) a.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * a.Cout + (long)which * a.Cout + cbase + cl] = s;
+    }
+  }
+}
+
+template <typename T, typename TO>
+static int launch_gather_t(GatherArgs& a, int gx, hipStream_t s) {
+  int ct16 = a.Cout >= 128 ? 8 : (a.Cout > 32 ? 4 : (a.Cout > 16 ? 2 : 1));
+  const int CT = ct16 * 16;
+  dim3 grid(gx, (a.Cout + CT - 1) / CT, a.nphase), block(256);
+  switch (ct16) {
+    case 1: hipLaunchKernelGGL((gather_gemm_kernel<T, TO, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((gather_gemm_kernel<T, TO, 2>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((gather_gemm_kernel<T, TO, 4>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((gather_gemm_kernel<T, TO, 8>), grid, block, 0, s, a); break;
+  }
+  int rc = check_launch("gather_gemm");
+  return rc ? rc : gx * a.nphase;
+}
+
+int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
+  const int VE = dt == DT_F32 ? 4 : 8;
+  if (a.Cin % VE != 0 || a.Cout % 4 != 0 || a.nphase < 1 || a.nphase > kMaxPhases) {
+    set_error("gather_gemm: unsupported Cin=%d Cout=%d nphase=%d", a.Cin, a.Cout, a.nphase);
+    return MMVAE_ERR_UNSUPPORTED;
+  }
+  if (a.pro_scale && a.Cin > 512) { set_error("gather_gemm: prologue needs Cin<=512"); return MMVAE_ERR_UNSUPPORTED; }
+  a.cin_vecs = a.Cin / VE;
+  int max_tiles = 0, ntap = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    const long M = (long)a.N * a.phases[p].Hq * a.phases[p].Wq;
+    if (M > 0x7fffffffL / 2) { set_error("gather_gemm: too many pixels"); return MMVAE_ERR_UNSUPPORTED; }
+    const int tiles = (int)((M + 127) / 128);
+    if (tiles > max_tiles) max_tiles = tiles;
+    ntap += a.phases[p].ntaps;
+  }
+  if (ntap > kMaxTaps) { set_error("gather_gemm: %d taps > %d", ntap, kMaxTaps); return MMVAE_ERR_UNSUPPORTED; }
+  if (max_tiles <= 0) return 1;
+  const int gx = max_tiles < kGatherMaxGridX ? max_tiles : kGatherMaxGridX;
+  if (dt == DT_F32) return launch_gather_t<float, float>(a, gx, s);
+  if (out_dt == DT_F32) return launch_gather_t<bf16_t, float>(a, gx, s);
+  return launch_gather_t<bf16_t, bf16_t>(a, gx, s);
+}
+
+// ============================================================================ wgrad
+// LDS rows are CHANNELS, kvecs are groups of VE consecutive pixels (transposed staging).
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int PK = KV * VE;       // pixels per K-step (64 bf16 / 32 f32)
+  __shared__ Vec16 sP[64 * KV];     // [TA<=64][8 kvecs]
+  __shared__ Vec16 sG[256 * KV];    // [TG*TB<=256][8 kvecs]
+  __shared__ int sPix[PK * 3];
+  __shared__ float sProP[2 * 256];
+  __shared__ float sProG[2 * 256];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4, r = lane & 15;
+  const int TA = a.TA16 * 16, TB = a.TB16 * 16, TG = a.TG;
+  const int nb_tiles = (a.Cb + TB - 1) / TB;
+  const int a0 = (blockIdx.y / nb_tiles) * TA, b0 = (blockIdx.y % nb_tiles) * TB;
+  const int tap0 = blockIdx.z * TG;
+  const int tg_n = min(TG, a.ntaps - tap0);
+  const T* __restrict__ P = reinterpret_cast<const T*>(a.P);
+  const T* __restrict__ G = reinterpret_cast<const T*>(a.G);
+  T* sPe = reinterpret_cast<T*>(sP);
+  T* sGe = reinterpret_cast<T*>(sG);
+  const bool proP = a.proP_scale != nullptr, proG = a.proG_scale != nullptr;
+  if (proP) for (int i = t; i < TA; i += 256) {
+    const bool ok = a0 + i < a.Ca;
+    sProP[i] = ok ? a.proP_scale[a0 + i] : 0.f; sProP[256 + i] = ok ? a.proP_shift[a0 + i] : 0.f;
+  }
+  if (proG) for (int i = t; i < TB; i += 256) {
+    const bool ok = b0 + i < a.Cb;
+    sProG[i] = ok ? a.proG_scale[b0 + i] : 0.f; sProG[256 + i] = ok ? a.proG_shift[b0 + i] : 0.f;
+  }
+
+  const int units = a.TA16 * a.TB16 * tg_n;
+  f32x4 acc[16];
+  int rowA[16], rowB[16];   // LDS fragment rows of unit u = wv + 4*i -> (tg, tb, ta)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    acc[i] = (f32x4){0, 0, 0, 0};
+    const int u = wv + 4 * i;
+    const int tg = u % tg_n, q = u / tg_n;
+    const int tb = q % a.TB16, ta = q / a.TB16;
+    rowA[i] = 16 * ta + r;
+    rowB[i] = tg * TB + 16 * tb + r;
+  }
+
+  const long m_begin = (long)blockIdx.x * a.pix_per_block;
+  const long m_end = min((long)a.M, m_begin + a.pix_per_block);
+  const int HpWp = a.Hp * a.Wp;
+  const int pvecs = TA / VE, gvecs = TB / VE;
+
+  for (long m0 = m_begin; m0 < m_end; m0 += PK) {
+    __syncthreads();   // previous step's fragment reads done; sPix reusable
+    if (t < PK) {
+      const long m = m0 + t;
+      if (m < m_end) {
+        const int n = (int)(m / HpWp), rem = (int)(m - (long)n * HpWp);
+        const int hp = rem / a.Wp, wp = rem - hp * a.Wp;
+        sPix[3 * t] = n * a.Hg * a.Wg;
+        sPix[3 * t + 1] = hp * a.stride - a.pad;
+        sPix[3 * t + 2] = wp * a.stride - a.pad;
+      } else {
+        sPix[3 * t] = -1; sPix[3 * t + 1] = 0; sPix[3 * t + 2] = 0;
+      }
+    }
+    __syncthreads();
+    // ---- stage P^T : [TA rows][PK pixels]
+    for (int v = t; v < PK * pvecs; v += 256) {
+      const int pk = v / pvecs, cv = v - pk * pvecs;
+      const int ch = cv * VE;
+      float f[VE];
+      const bool ok = (m0 + pk) < m_end && (a0 + ch) < a.Ca;
+      if (ok) {
+        const Vec16 q = *reinterpret_cast<const Vec16*>(P + ((m0 + pk) * a.Ca + a0 + ch));
+        Elem<T>::unpack(q, f);
+        if (proP) {
+#pragma unroll
+          for (int j = 0; j < VE; ++j) {
+            float x = f[j] * sProP[ch + j] + sProP[256 + ch + j];
+            f[j] = a.proP_relu ? fmaxf(x, 0.f) : x;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) f[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        const int row = ch + j;
+        Elem<T>::store(sPe + (long)lds_slot(row, pk / VE) * VE + (pk % VE), f[j]);
+      }
+    }
+    // ---- stage G_tap^T : [tg][TB rows][PK pixels]
+    for (int v = t; v < tg_n * PK * gvecs; v += 256) {
+      const int tg = v / (PK * gvecs), rem = v - tg * (PK * gvecs);
+      const int pk = rem / gvecs, cv = rem - pk * gvecs;
+      const int ch = cv * VE;
+      const int tap = tap0 + tg, kh = tap / a.ksz, kw = tap - kh * a.ksz;
+      const int base = sPix[3 * pk], hg = sPix[3 * pk + 1] + kh, wg = sPix[3 * pk + 2] + kw;
+      const bool ok = base >= 0 && hg >= 0 && hg < a.Hg && wg >= 0 && wg < a.Wg && (b0 + ch) < a.Cb;
+      float f[VE];
+      if (ok) {
+        const Vec16 q = *reinterpret_cast<const Vec16*>(G + ((long)(base + hg * a.Wg + wg) * a.Cb + b0 + ch));
+        Elem<T>::unpack(q, f);
+        if (proG) {
+#pragma unroll
+          for (int j = 0; j < VE; ++j) {
+            float x = f[j] * sProG[ch + j] + sProG[256 + ch + j];
+            f[j] = a.proG_relu ? fmaxf(x, 0.f) : x;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) f[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        const int row = tg * TB + ch + j;
+        Elem<T>::store(sGe + (long)lds_slot(row, pk / VE) * VE + (pk % VE), f[j]);
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: unit u = wv + 4*i -> (tg, tb, ta)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int u = wv + 4 * i;
+      if (u < units) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int kvs = 4 * k2 + g;
+          const Vec16 af = sP[lds_slot(rowA[i], kvs)];
+          const Vec16 bf = sG[lds_slot(rowB[i], kvs)];
+          acc[i] = Mma<T>::run(af, bf, acc[i]);
+        }
+      }
+    }
+  }
+  // ---- epilogue: lane holds a = 16ta + 4g + j, b = 16tb + r
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int u = wv + 4 * i;
+    if (u < units) {
+      const int tg = u % tg_n, q = u / tg_n;
+      const int tb = q % a.TB16, ta = q / a.TB16;
+      const int bb = b0 + 16 * tb + r;
+      if (bb < a.Cb_valid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int aa = a0 + 16 * ta + 4 * g + j;
+          if (aa < a.Ca) atomicAdd(a.dW + (long)aa * a.sA + (long)bb * a.sB + a.tap_off[tap0 + tg], acc[i][j] * a.scale);
+        }
+      }
+    }
+  }
+}
+
+int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
+  const int VE = dt == DT_F32 ? 4 : 8;
+  if (a.Ca % VE != 0 || a.Cb % VE != 0 || a.ntaps > 25 || a.ntaps < 1) {
+    set_error("wgrad: unsupported Ca=%d Cb=%d ntaps=%d", a.Ca, a.Cb, a.ntaps);
+    return MMVAE_ERR_UNSUPPORTED;
+  }
+  a.M = a.N * a.Hp * a.Wp;
+  if (a.Cb_valid <= 0 || a.Cb_valid > a.Cb) a.Cb_valid = a.Cb;
+  if (a.M <= 0) return MMVAE_OK;
+  const int TA = a.Ca >= 64 ? 64 : ((a.Ca + 15) / 16) * 16;
+  const int TB = a.Cb >= 64 ? 64 : ((a.Cb + 15) / 16) * 16;
+  a.TA16 = TA / 16; a.TB16 = TB / 16;
+  int tg = 256 / TB;                                   // LDS rows for G
+  const int max_units_tg = 64 / (a.TA16 * a.TB16);     // <= 16 accumulators per wave
+  if (tg > max_units_tg) tg = max_units_tg;
+  if (tg > a.ntaps) tg = a.ntaps;
+  if (tg < 1) tg = 1;
+  a.TG = tg;
+  const int tiles = ((a.Ca + TA - 1) / TA) * ((a.Cb + TB - 1) / TB);
+  const int zg = (a.ntaps + tg - 1) / tg;
+  const int PK = KV * VE;
+  const long ksteps = ((long)a.M + PK - 1) / PK;
+  long want = 1024 / ((long)tiles * zg);               // pixel chunks so that ~1024 blocks exist
+  if (want < 1) want = 1;
+  if (want > ksteps) want = ksteps;
+  long steps_per = (ksteps + want - 1) / want;
+  a.pix_per_block = (int)(steps_per * PK);
+  const int gx = (int)(((long)a.M + a.pix_per_block - 1) / a.pix_per_block);
+  dim3 grid(gx, tiles, zg), block(256);
+  if (dt == DT_F32) hipLaunchKernelGGL((wgrad_kernel<float>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((wgrad_kernel<bf16_t>), grid, block, 0, s, a);
+  return check_launch("wgrad");
+}
+
+// ============================================================================ weight packing
+template <typename T>
+__global__ void pack_kernel(PackArgs a) {
+  const long total = (long)a.cols * a.ntaps * a.K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % a.K);
+    const long q = i / a.K;
+    const int tp = (int)(q % a.ntaps);
+    const int col = (int)(q / a.ntaps);
+    const float v = a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale;
+    Elem<T>::store(reinterpret_cast<T*>(a.dst) + i, v);
+  }
+}
+
+int launch_pack(int dt, const PackArgs& a, hipStream_t s) {
+  const long total = (long)a.cols * a.ntaps * a.K;
+  if (total <= 0) return MMVAE_OK;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (dt == DT_F32) hipLaunchKernelGGL((pack_kernel<float>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((pack_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, a);
+  return check_launch("pack");
+}
+
+}  // namespace mmvae

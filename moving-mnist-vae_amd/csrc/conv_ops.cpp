@@ -1,0 +1,119 @@
+#include "conv_ops.hpp"
+
+#include <cstring>
+
+namespace mmvae {
+
+#define MM_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ < 0) return rc__;  \
+  } while (0)
+
+// stride phases of an "up" (transposed) gather: for output phase (ph,pw) the kernel taps with (ph+p-kh) % s == 0
+struct UpPhase { int ph, pw; int ntaps; int kh[16], kw[16], dh[16], dw[16]; };
+static int up_phases(int k, int s, int p, UpPhase* out) {
+  int n = 0;
+  for (int ph = 0; ph < s; ++ph)
+    for (int pw = 0; pw < s; ++pw) {
+      UpPhase& u = out[n++];
+      u.ph = ph; u.pw = pw; u.ntaps = 0;
+      for (int kh = 0; kh < k; ++kh) {
+        const int th = ph + p - kh;
+        if (((th % s) + s) % s != 0) continue;
+        for (int kw = 0; kw < k; ++kw) {
+          const int tw = pw + p - kw;
+          if (((tw % s) + s) % s != 0) continue;
+          u.kh[u.ntaps] = kh; u.kw[u.ntaps] = kw;
+          u.dh[u.ntaps] = th / s; u.dw[u.ntaps] = tw / s;   // exact divisions
+          ++u.ntaps;
+        }
+      }
+    }
+  return n;
+}
+
+
+int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s) {
+  PackArgs a; std::memset(&a, 0, sizeof(a));
+  const int kk = g.k * g.k;
+  if (kk > kMaxTaps) { set_error("pack_down: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
+  a.src = w; a.dst = dst;
+  a.cols = g.D0; a.K = g.D1; a.ntaps = kk; a.s_col = g.D1 * kk; a.s_k = kk; a.scale = 1.f;
+  for (int t = 0; t < kk; ++t) a.tap_off[t] = t;
+  return launch_pack(dt, a, s);
+}
+
+int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s) {
+  if (g.s > 2 || g.k * g.k > kMaxTaps) { set_error("pack_up: k=%d s=%d unsupported", g.k, g.s); return MMVAE_ERR_UNSUPPORTED; }
+  UpPhase ph[4];
+  const int np = up_phases(g.k, g.s, g.p, ph);
+  const int kk = g.k * g.k;
+  const long e = (long)dtype_size(dt);
+  long off = 0;
+  for (int i = 0; i < np; ++i) {
+    if (ph[i].ntaps == 0) continue;
+    PackArgs a; std::memset(&a, 0, sizeof(a));
+    a.src = w; a.dst = static_cast<char*>(dst) + off * e;
+    a.cols = g.D1; a.K = g.D0; a.ntaps = ph[i].ntaps; a.s_col = kk; a.s_k = g.D1 * kk; a.scale = 1.f;
+    for (int t = 0; t < ph[i].ntaps; ++t) a.tap_off[t] = ph[i].kh[t] * g.k + ph[i].kw[t];
+    MM_TRY(launch_pack(dt, a, s));
+    off += (long)g.D1 * ph[i].ntaps * g.D0;
+  }
+  return MMVAE_OK;
+}
+
+int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
+                const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s) {
+  GatherArgs a; std::memset(&a, 0, sizeof(a));
+  if (g.k * g.k > kMaxTaps) { set_error("run_down: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
+  a.x = L; a.w = packed; a.y = S;
+  a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
+  a.N = N; a.Hi = Hl; a.Wi = Wl; a.Cin = g.D1; a.Ho = Hs; a.Wo = Ws; a.Cout = g.D0; a.SI = g.s; a.SO = 1;
+  a.nphase = 1;
+  a.phases[0] = Phase{0, 0, Hs, Ws, g.k * g.k, 0, 0};
+  for (int kh = 0; kh < g.k; ++kh)
+    for (int kw = 0; kw < g.k; ++kw) a.taps[kh * g.k + kw] = Tap{kh - g.p, kw - g.p};
+  return launch_gather_gemm(dt, out_dt, a, s);
+}
+
+int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
+              const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s) {
+  if (g.s > 2 || g.k * g.k > kMaxTaps) { set_error("run_up: k=%d s=%d unsupported", g.k, g.s); return MMVAE_ERR_UNSUPPORTED; }
+  GatherArgs a; std::memset(&a, 0, sizeof(a));
+  a.x = S; a.w = packed; a.y = L;
+  a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
+  a.N = N; a.Hi = Hs; a.Wi = Ws; a.Cin = g.D0; a.Ho = Hl; a.Wo = Wl; a.Cout = g.D1; a.SI = 1; a.SO = g.s;
+  UpPhase ph[4];
+  const int np = up_phases(g.k, g.s, g.p, ph);
+  long off = 0; int tap0 = 0; a.nphase = 0;
+  for (int i = 0; i < np; ++i) {
+    const int Hq = Hl > ph[i].ph ? (Hl - ph[i].ph + g.s - 1) / g.s : 0;
+    const int Wq = Wl > ph[i].pw ? (Wl - ph[i].pw + g.s - 1) / g.s : 0;
+    const bool skip = (ph[i].ntaps == 0 && accumulate) || Hq == 0 || Wq == 0;
+    if (!skip) {
+      a.phases[a.nphase++] = Phase{ph[i].ph, ph[i].pw, Hq, Wq, ph[i].ntaps, tap0, off};
+      for (int t = 0; t < ph[i].ntaps; ++t) a.taps[tap0 + t] = Tap{ph[i].dh[t], ph[i].dw[t]};
+      tap0 += ph[i].ntaps;
+    }
+    off += (long)g.D1 * ph[i].ntaps * g.D0;
+  }
+  if (a.nphase == 0) return 1;
+  return launch_gather_gemm(dt, dt, a, s);
+}
+
+int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
+                 const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s) {
+  WgradArgs a; std::memset(&a, 0, sizeof(a));
+  const int kk = g.k * g.k;
+  if (kk > 25) { set_error("wgrad: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
+  a.P = P; a.G = G; a.dW = dW;
+  a.proP_scale = proP_s; a.proP_shift = proP_b; a.proP_relu = proP_relu;
+  a.proG_scale = proG_s; a.proG_shift = proG_b; a.proG_relu = proG_relu;
+  a.N = N; a.Hp = Hs; a.Wp = Ws; a.Ca = g.D0; a.Hg = Hl; a.Wg = Wl; a.Cb = g.D1; a.Cb_valid = g.D1;
+  a.stride = g.s; a.pad = g.p; a.ksz = g.k; a.sA = g.D1 * kk; a.sB = kk; a.ntaps = kk; a.scale = 1.f;
+  for (int t = 0; t < kk; ++t) a.tap_off[t] = t;
+  return launch_wgrad(dt, a, s);
+}
+
+}  // namespace mmvae

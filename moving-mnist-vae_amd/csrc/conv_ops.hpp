@@ -1,0 +1,24 @@
+// Geometry-level conv operations shared by the network orchestrator and the single-op C ABI.
+// A conv-like weight [D0][D1][k][k] relates a "small" tensor S [N,Hs,Ws,D0] and a "large" tensor L [N,Hl,Wl,D1]
+// with Hs = floor((Hl + 2p - k)/s) + 1:
+//   Conv2d          weight (out,in,k,k):  forward = down(L->S), dgrad = up(S->L),   wgrad(P = dy (S), G = x (L))
+//   ConvTranspose2d weight (in,out,k,k):  forward = up(S->L),   dgrad = down(L->S), wgrad(P = x (S),  G = dy (L))
+#pragma once
+#include "kernels.hpp"
+
+namespace mmvae {
+
+struct ConvGeom { int D0, D1, k, s, p; };
+
+inline int conv_down_size(int H, int k, int s, int p) { return (H + 2 * p - k) / s + 1; }
+// packed element counts (both equal numel(weight)); 16-byte alignment is the caller's job
+int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s);
+int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s);
+int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
+                const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s);
+int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
+              const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s);
+int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
+                 const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s);
+
+}  // namespace mmvae

@@ -1,0 +1,146 @@
+// Host-side launch API of the HIP kernels (internal; the public C ABI is include/mmvae.h).
+#pragma once
+#include "common.hpp"
+
+namespace mmvae {
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------- gather GEMM
+// y[n, hq*SO+ph, wq*SO+pw, co] (+)= bias[co] + sum_{t<ntaps} sum_{ci}
+//        pro(x[n, hq*SI+dh[t], wq*SI+dw[t], ci]) * w[co][t][ci]
+// with zero for out-of-range input coordinates (zero padding is applied AFTER pro()).
+// Covers Conv2d forward (SI=stride, SO=1, one launch) and every stride-phase of a
+// transposed convolution / data-gradient (SI=1, SO=stride, one launch per phase).
+struct Tap { int dh, dw; };
+constexpr int kMaxTaps = 16;     // over all phases of one launch
+constexpr int kMaxPhases = 4;
+struct Phase { int ph, pw, Hq, Wq, ntaps, tap0; long w_off; /* element offset of this phase's [Cout][ntaps*Cin] matrix */ };
+struct GatherArgs {
+  const void* x; const void* w; void* y;
+  const float* pro_scale; const float* pro_shift; int pro_relu;
+  const float* bias;
+  float* stats;            // [gridDim.z*gridDim.x][2][Cout] partial (sum, sumsq) of the f32 results, or null
+  int accumulate;          // y += result
+  int N, Hi, Wi, Cin, Ho, Wo, Cout;
+  int SI, SO;
+  int nphase; Phase phases[kMaxPhases]; Tap taps[kMaxTaps];
+  int cin_vecs;
+};
+// out_dt: dtype of y (may be DT_F32 while x/w are bf16).  Returns the number of stats partial rows (>0) or an error (<0).
+int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s);
+constexpr int kGatherMaxGridX = 1024;
+
+// ---------------------------------------------------------------- wgrad
+// dW[a*sA + b*sB + tap_off[t]] += scale * sum_{n,hp,wp} proP(P[n,hp,wp,a]) * proG(G[n, hp*stride-pad+kh_t, wp*stride-pad+kw_t, b])
+struct WgradArgs {
+  const void* P; const void* G; float* dW;
+  const float* proP_scale; const float* proP_shift; int proP_relu;
+  const float* proG_scale; const float* proG_shift; int proG_relu;
+  int N, Hp, Wp, Ca, Hg, Wg, Cb;
+  int Cb_valid;            // b >= Cb_valid is computed but not written (0 -> Cb)
+  int stride, pad, ksz;
+  int sA, sB; int ntaps; int tap_off[25];
+  float scale;
+  int M, pix_per_block;
+  int TA16, TB16, TG;      // tile config chosen by the launcher
+};
+int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
+
+// ---------------------------------------------------------------- weight packing
+// dst[(col*ntaps + t)*K + k] = T(scale * src[col*s_col + k*s_k + tap_off[t]])
+struct PackArgs {
+  const float* src; void* dst; int cols, K, ntaps; int s_col, s_k; int tap_off[kMaxTaps]; float scale;
+};
+int launch_pack(int dt, const PackArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- direct stem / tail kernels
+// stem: Conv2d(1 -> Cout<=32 multiple of 8, k5 s2 p2), x [N,H,W] (T) -> y [N,Ho,Wo,Cout] (T)
+int launch_stem_fwd(int dt, const void* x, const float* w /*[Cout][25] f32*/, void* y, int N, int H, int W, int Ho, int Wo,
+                    int Cout, hipStream_t s);
+// im2col of the 1-channel image for the stem weight gradient: col[m][32] (25 taps, 7 zero pads), T
+int launch_stem_im2col(int dt, const void* x, void* col, int N, int H, int W, int Ho, int Wo, hipStream_t s);
+// tail: Conv2d(Cin=16 -> OC<=8, k3 s1 p1, bias), x [N,H,W,16] (T) -> y [N,OC,H,W] f32 (NCHW)
+int launch_tail_fwd(int dt, const void* x, const float* w /*[OC][16][3][3]*/, const float* bias, float* y, int N, int H, int W,
+                    int OC, hipStream_t s);
+// dx[n,h,w,ci] = sum_{oc,kh,kw} dy[n,oc,h+1-kh,w+1-kw] * w[oc][ci][kh][kw]
+int launch_tail_dgrad(int dt, const float* dy, const float* w, void* dx, int N, int H, int W, int OC, hipStream_t s);
+// dW[oc][ci][kh][kw] += sum dy[n,oc,h,w]*x[n,h-1+kh,w-1+kw,ci];  dbias[oc] += sum dy
+int launch_tail_wgrad(int dt, const void* x, const float* dy, float* dW, float* dbias, int N, int H, int W, int OC,
+                      hipStream_t s);
+
+// ---------------------------------------------------------------- BatchNorm pieces
+// per-channel (sum, sumsq) partials over an NHWC tensor of T: out [nparts][2][C]; returns nparts
+int launch_chan_stats_nhwc(int dt, const void* y, long npix, int C, float* partials, hipStream_t s);
+int chan_stats_parts(long npix, int C);
+// same for an NCHW f32 tensor [N][C][HW]
+int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials, hipStream_t s);
+// training finalize: partials -> mean/istd/scale/shift; running stats update (momentum, unbiased var); nbt += 1
+struct BnFinalizeArgs {
+  const float* partials; int nparts; int C; double count;
+  const float* gamma; const float* beta; float* running_mean; float* running_var; long long* nbt;
+  float* mean; float* istd; float* scale; float* shift; float momentum, eps;
+};
+int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+// eval: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
+int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                          float* scale, float* shift, hipStream_t s);
+// out = relu(a*sa + ba + b*sb + bb)   (NHWC, T)
+int launch_join_fwd(int dt, const void* a, const float* sa, const float* ba, const void* b, const float* sb, const float* bb,
+                    void* out, long npix, int C, hipStream_t s);
+// out = relu?(a*sa + ba)
+int launch_affine_act(int dt, const void* a, const float* sa, const float* ba, int relu, void* out, long npix, int C,
+                      hipStream_t s);
+// BN-backward reductions.  g = dout * mask, mask = (out > 0) if out!=null else (y0*msk_scale+msk_shift > 0) if msk_scale else 1.
+// partials [nparts][1+NY][C]: sum g, sum g*y0, (sum g*y1).  Returns nparts.
+int launch_bn_bwd_reduce(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
+                         const void* y0, const void* y1, long npix, int C, float* partials, hipStream_t s);
+// coefficients for dy = A*g + B*y + Cc, plus dgamma/dbeta (accumulated into grads with +=)
+struct BnBwdFinalizeArgs {
+  const float* partials; int nparts; int C; int which /*0: y0, 1: y1*/; int ny; double count;
+  const float* gamma; const float* mean; const float* istd; float* dgamma; float* dbeta; float* coefA; float* coefB; float* coefC;
+};
+int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
+// dy0 = A0*g + B0*y0 + C0 ; (dy1 = A1*g + B1*y1 + C1)
+int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
+                        const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
+                        const void* y1, const float* A1, const float* B1, const float* C1, void* dy1,
+                        long npix, int C, hipStream_t s);
+// NCHW f32 variants for the output BatchNorm (decoder.bn2): recon = raw*scale+shift ; backward pieces
+int launch_affine_nchw(const float* raw, const float* scale, const float* shift, float* out, int N, int C, int HW, hipStream_t s);
+int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s);
+int launch_bn_bwd_apply_nchw(const float* dout, const float* y, const float* A, const float* B, const float* Cc, float* dy,
+                             int N, int C, int HW, hipStream_t s);
+
+// ---------------------------------------------------------------- latent / loss
+// enc = mu + exp(0.5*logvar)*eps (f32 and T copies); kl_partial: -0.5*sum(lv - exp(lv) - mu^2 + 1) (one float, atomically added)
+int launch_rsample_fwd(int dt, const float* mu, const float* logvar, const float* eps, float* enc_f32, void* enc_t, long n,
+                       hipStream_t s);
+int launch_rsample_bwd(const float* d_enc, const float* logvar, const float* eps, float* d_mu, float* d_logvar, long n, hipStream_t s);
+int launch_kl_fwd(const float* mu, const float* logvar, long n, double* out, hipStream_t s);
+// d_mu += coef*mu ; d_logvar += coef*0.5*(exp(lv)-1)   (coef = kl_weight * upstream / N)
+int launch_kl_bwd(const float* mu, const float* logvar, float coef, const float* gscale, float* d_mu, float* d_logvar, long n, hipStream_t s);
+// Gaussian NLL: out[0] += sum 0.5*((t-r)/sigma)^2 + log(sigma) + 0.5*log(2pi);  d_r = coef*(r-t)/sigma^2
+int launch_gauss_nll_fwd(const float* r, const float* t, long n, float sigma, double* out, hipStream_t s);
+int launch_gauss_nll_bwd(const float* r, const float* t, long n, float sigma, float coef, const float* gscale, float* d_r, hipStream_t s);
+// weighted cross entropy over NCHW logits [N][Q][HW], int64 targets [N][HW]: out += sum w[t]*(lse - r[t])
+int launch_ce_fwd(const float* r, const long long* t, const float* w, int N, int Q, int HW, double* out, hipStream_t s);
+int launch_ce_bwd(const float* r, const long long* t, const float* w, int N, int Q, int HW, float coef, const float* gscale, float* d_r,
+                  hipStream_t s);
+// MMD (sums): out += sum_ij k(x_i,x_j) + sum_ij k(y_i,y_j) - 2 sum_ij k(x_i,y_j), k = exp(-|a-b|^2/d^2)
+int launch_mmd_fwd(const float* x, const float* y, int n, int d, double* out, hipStream_t s);
+// d_y[j] += coef * d(mmd)/d(y_j)
+int launch_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, hipStream_t s);
+
+// ---------------------------------------------------------------- optimiser / misc
+struct AdamArgs { float* p; const float* g; float* m; float* v; long n; float lr, beta1, beta2, eps, weight_decay; float bc1, bc2; float grad_scale; };
+int launch_adam(const AdamArgs& a, hipStream_t s);
+// labels (int64) -> image T [(l - mean)/std] (+ f32 copy for the Gaussian target)
+int launch_normalise(int dt, const long long* labels, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s);
+int launch_convert(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s);
+int launch_concat2_to_t(int dt, const float* a, const float* b, int rows, int ca, int cb, void* out, hipStream_t s);
+int launch_loss_finish(const double* acc, float* out, float nll, float klc, float mmdc, float n, hipStream_t s);
+int launch_double_to_float(const double* in, float* out, int n, float scale, hipStream_t s);
+
+}  // namespace mmvae

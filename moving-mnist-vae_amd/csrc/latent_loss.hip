@@ -1,0 +1,363 @@
+// Latent-space and loss kernels: reparameterisation, KL, Gaussian NLL / weighted cross-entropy, RBF-MMD,
+// plus the flat Adam step and small conversion helpers.  All scalar reductions accumulate in f64 through one
+// atomicAdd per block into a caller-zeroed accumulator.
+#include "kernels.hpp"
+
+namespace mmvae {
+
+static int rblocks(long n, int cap = 1024) {
+  long b = (n + 1023) / 1024;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+__device__ __forceinline__ void block_atomic_add_d(double v, double* out) {
+  __shared__ double sred[4];
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sred[wid] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sred[w];
+    atomicAdd(out, s);
+  }
+}
+
+// ---------------------------------------------------------------- reparameterisation (model.py:148-150)
+template <typename T>
+__global__ void rsample_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ eps,
+                                   float* __restrict__ enc, T* __restrict__ enc_t, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float e = mu[i] + eps[i] * expf(lv[i] * 0.5f);
+    enc[i] = e;
+    if (enc_t) Elem<T>::store(enc_t + i, e);
+  }
+}
+int launch_rsample_fwd(int dt, const float* mu, const float* logvar, const float* eps, float* enc_f32, void* enc_t, long n, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  if (dt == DT_F32) hipLaunchKernelGGL((rsample_fwd_kernel<float>), dim3(rblocks(n)), dim3(256), 0, s, mu, logvar, eps, enc_f32, (float*)enc_t, n);
+  else hipLaunchKernelGGL((rsample_fwd_kernel<bf16_t>), dim3(rblocks(n)), dim3(256), 0, s, mu, logvar, eps, enc_f32, (bf16_t*)enc_t, n);
+  return check_launch("rsample_fwd");
+}
+__global__ void rsample_bwd_kernel(const float* __restrict__ d_enc, const float* __restrict__ lv, const float* __restrict__ eps,
+                                   float* __restrict__ d_mu, float* __restrict__ d_lv, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = d_enc[i];
+    d_mu[i] = g;
+    d_lv[i] = g * eps[i] * 0.5f * expf(lv[i] * 0.5f);
+  }
+}
+int launch_rsample_bwd(const float* d_enc, const float* logvar, const float* eps, float* d_mu, float* d_logvar, long n, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(rsample_bwd_kernel, dim3(rblocks(n)), dim3(256), 0, s, d_enc, logvar, eps, d_mu, d_logvar, n);
+  return check_launch("rsample_bwd");
+}
+
+// ---------------------------------------------------------------- KL (model.py:364-365)
+__global__ void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, long n, double* out) {
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float l = lv[i], m = mu[i];
+    acc += (double)(l - expf(l) - m * m + 1.0f);
+  }
+  block_atomic_add_d(-0.5 * acc, out);
+}
+int launch_kl_fwd(const float* mu, const float* logvar, long n, double* out, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(rblocks(n, 256)), dim3(256), 0, s, mu, logvar, n, out);
+  return check_launch("kl_fwd");
+}
+__global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv, float coef, const float* __restrict__ gs,
+                              float* __restrict__ d_mu, float* __restrict__ d_lv, long n) {
+  if (gs) coef *= gs[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    d_mu[i] = coef * mu[i];
+    d_lv[i] = coef * 0.5f * (expf(lv[i]) - 1.0f);
+  }
+}
+int launch_kl_bwd(const float* mu, const float* logvar, float coef, const float* gscale, float* d_mu, float* d_logvar, long n, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(rblocks(n)), dim3(256), 0, s, mu, logvar, coef, gscale, d_mu, d_logvar, n);
+  return check_launch("kl_bwd");
+}
+
+// ---------------------------------------------------------------- Gaussian NLL (model.py:403)
+__global__ void gauss_nll_fwd_kernel(const float* __restrict__ r, const float* __restrict__ t, long n, float inv2var, float cst,
+                                     double* out) {
+  double acc = 0.0;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(r)[i], b = reinterpret_cast<const float4*>(t)[i];
+    const float d0 = b.x - a.x, d1 = b.y - a.y, d2 = b.z - a.z, d3 = b.w - a.w;
+    acc += (double)((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long i = n4 << 2; i < n; ++i) { const float d = t[i] - r[i]; acc += (double)(d * d); }
+  block_atomic_add_d(acc * (double)inv2var, out);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(out, (double)cst * (double)n);
+}
+int launch_gauss_nll_fwd(const float* r, const float* t, long n, float sigma, double* out, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  const float var = sigma * sigma;
+  const float cst = logf(sigma) + (float)log(sqrt(2.0 * 3.14159265358979323846));
+  hipLaunchKernelGGL(gauss_nll_fwd_kernel, dim3(rblocks(n / 4 + 1)), dim3(256), 0, s, r, t, n, 1.0f / (2.0f * var), cst, out);
+  return check_launch("gauss_nll_fwd");
+}
+__global__ void gauss_nll_bwd_kernel(const float* __restrict__ r, const float* __restrict__ t, long n, float k, const float* __restrict__ gs,
+                                     float* __restrict__ d_r) {
+  if (gs) k *= gs[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d_r[i] = k * (r[i] - t[i]);
+}
+int launch_gauss_nll_bwd(const float* r, const float* t, long n, float sigma, float coef, const float* gscale, float* d_r, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(gauss_nll_bwd_kernel, dim3(rblocks(n, 2048)), dim3(256), 0, s, r, t, n, coef / (sigma * sigma), gscale, d_r);
+  return check_launch("gauss_nll_bwd");
+}
+
+// ---------------------------------------------------------------- weighted cross entropy (model.py:400-401)
+template <bool BWD>
+__global__ void ce_kernel(const float* __restrict__ r, const long long* __restrict__ t, const float* __restrict__ w, int N, int Q, int HW,
+                          float coef, const float* __restrict__ gs, double* out, float* __restrict__ d_r) {
+  double acc = 0.0;
+  if (BWD && gs) coef *= gs[0];
+  const long total = (long)N * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / HW), p = (int)(i - (long)n * HW);
+    const float* rp = r + (long)n * Q * HW + p;
+    const int tg = (int)t[i];
+    float mx = rp[0];
+    for (int q = 1; q < Q; ++q) mx = fmaxf(mx, rp[(long)q * HW]);
+    float se = 0.f;
+    for (int q = 0; q < Q; ++q) se += expf(rp[(long)q * HW] - mx);
+    const float lse = mx + logf(se);
+    const float wt = w ? w[tg] : 1.f;
+    if (!BWD) {
+      acc += (double)(wt * (lse - rp[(long)tg * HW]));
+    } else {
+      float* dp = d_r + (long)n * Q * HW + p;
+      for (int q = 0; q < Q; ++q) {
+        const float sm = expf(rp[(long)q * HW] - lse);
+        dp[(long)q * HW] = coef * wt * (sm - (q == tg ? 1.f : 0.f));
+      }
+    }
+  }
+  if (!BWD) block_atomic_add_d(acc, out);
+}
+int launch_ce_fwd(const float* r, const long long* t, const float* w, int N, int Q, int HW, double* out, hipStream_t s) {
+  if ((long)N * HW <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL((ce_kernel<false>), dim3(rblocks((long)N * HW)), dim3(256), 0, s, r, t, w, N, Q, HW, 0.f, (const float*)nullptr, out, (float*)nullptr);
+  return check_launch("ce_fwd");
+}
+int launch_ce_bwd(const float* r, const long long* t, const float* w, int N, int Q, int HW, float coef, const float* gscale, float* d_r,
+                  hipStream_t s) {
+  if ((long)N * HW <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL((ce_kernel<true>), dim3(rblocks((long)N * HW, 2048)), dim3(256), 0, s, r, t, w, N, Q, HW, coef, gscale, (double*)nullptr, d_r);
+  return check_launch("ce_bwd");
+}
+
+// ---------------------------------------------------------------- RBF MMD (model.py:367-383), never materialises (N,N,d)
+// 64x64 pair tile per block, 4x4 pairs per thread, d staged through LDS in chunks of 32.
+__global__ __launch_bounds__(256) void mmd_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, int d, double* out) {
+  __shared__ float sA[64][33];
+  __shared__ float sB[64][33];
+  const int which = blockIdx.z;     // 0: xx, 1: yy, 2: xy
+  const float* A = which == 1 ? y : x;
+  const float* B = which == 0 ? x : y;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (int k0 = 0; k0 < d; k0 += 32) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < 64 * 32; v += 256) {
+      const int rr = v >> 5, kk = v & 31;
+      sA[rr][kk] = (i0 + rr < n && k0 + kk < d) ? A[(long)(i0 + rr) * d + k0 + kk] : 0.f;
+      sB[rr][kk] = (j0 + rr < n && k0 + kk < d) ? B[(long)(j0 + rr) * d + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = sA[ti + 16 * a][kk];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = sB[tj + 16 * b][kk];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { const float df = av[a] - bv[b]; acc[a][b] += df * df; }
+    }
+  }
+  const float inv = 1.0f / ((float)d * (float)d);
+  double sum = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (i0 + ti + 16 * a < n && j0 + tj + 16 * b < n) sum += (double)expf(-acc[a][b] * inv);
+  block_atomic_add_d(which == 2 ? -2.0 * sum : sum, out);
+}
+int launch_mmd_fwd(const float* x, const float* y, int n, int d, double* out, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  const int tiles = (n + 63) / 64;
+  hipLaunchKernelGGL(mmd_fwd_kernel, dim3(tiles, tiles, 3), dim3(256), 0, s, x, y, n, d, out);
+  return check_launch("mmd_fwd");
+}
+
+// d mmd / d y_j = -(4/d^2) sum_i k(y_i,y_j)(y_j - y_i) + (4/d^2) sum_i k(x_i,y_j)(y_j - x_i).  One block per j.
+__global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, int d, float coef,
+                                                      const float* __restrict__ gs, float* __restrict__ d_y) {
+  extern __shared__ float sm[];
+  if (gs) coef *= gs[0];
+  float* syj = sm;            // [d]
+  float* wy = sm + d;         // [chunk]
+  float* wx = wy + 1024;      // [chunk]
+  const int j = blockIdx.x;
+  for (int k = threadIdx.x; k < d; k += blockDim.x) syj[k] = y[(long)j * d + k];
+  const float inv = 1.0f / ((float)d * (float)d);
+  float accv[2] = {0.f, 0.f};   // up to 512 dims with 256 threads
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    __syncthreads();
+    for (int ii = threadIdx.x; ii < 1024; ii += blockDim.x) {
+      const int i = i0 + ii;
+      float ky = 0.f, kx = 0.f;
+      if (i < n) {
+        float dy2 = 0.f, dx2 = 0.f;
+        for (int k = 0; k < d; ++k) {
+          const float a = y[(long)i * d + k] - syj[k], b = x[(long)i * d + k] - syj[k];
+          dy2 += a * a; dx2 += b * b;
+        }
+        ky = expf(-dy2 * inv); kx = expf(-dx2 * inv);
+      }
+      wy[ii] = ky; wx[ii] = kx;
+    }
+    __syncthreads();
+    const int cnt = min(1024, n - i0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = threadIdx.x + 256 * q;
+      if (k < d) {
+        float a = 0.f;
+        const float yj = syj[k];
+        for (int ii = 0; ii < cnt; ++ii) {
+          const long row = (long)(i0 + ii) * d + k;
+          a += -wy[ii] * (yj - y[row]) + wx[ii] * (yj - x[row]);
+        }
+        accv[q] += a;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int k = threadIdx.x + 256 * q;
+    if (k < d) d_y[(long)j * d + k] += coef * 4.0f * inv * accv[q];
+  }
+}
+int launch_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  if (d > 512) { set_error("mmd_bwd: latent dim %d > 512", d); return MMVAE_ERR_UNSUPPORTED; }
+  const size_t smb = (size_t)(d + 2048) * sizeof(float);
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(n), dim3(256), smb, s, x, y, n, d, coef, gscale, d_y);
+  return check_launch("mmd_bwd");
+}
+
+// ---------------------------------------------------------------- Adam (torch.optim.Adam defaults, main.py:468)
+__global__ void adam_kernel(AdamArgs a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+    float g = a.g[i] * a.grad_scale;
+    float p = a.p[i];
+    if (a.weight_decay != 0.f) g += a.weight_decay * p;
+    float m = a.m[i], v = a.v[i];
+    m = m + (g - m) * (1.0f - a.beta1);                 // exp_avg.lerp_(grad, 1-beta1)
+    v = v * a.beta2 + (1.0f - a.beta2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+    const float denom = sqrtf(v) / a.bc2 + a.eps;       // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+    p = p - (a.lr / a.bc1) * (m / denom);               // param.addcdiv_(exp_avg, denom, value=-step_size)
+    a.p[i] = p; a.m[i] = m; a.v[i] = v;
+  }
+}
+int launch_adam(const AdamArgs& a, hipStream_t s) {
+  if (a.n <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(rblocks(a.n, 2048)), dim3(256), 0, s, a);
+  return check_launch("adam");
+}
+
+// ---------------------------------------------------------------- input normalisation (main.py:383-387)
+template <typename T>
+__global__ void normalise_kernel(const long long* __restrict__ labels, long n, float mean, float stdv, T* __restrict__ img,
+                                 float* __restrict__ img32) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = ((float)labels[i] - mean) / stdv;
+    if (img) Elem<T>::store(img + i, v);
+    if (img32) img32[i] = v;
+  }
+}
+int launch_normalise(int dt, const long long* labels, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float>), dim3(rblocks(n, 2048)), dim3(256), 0, s, labels, n, mean, stdv, (float*)img_t, img_f32);
+  else hipLaunchKernelGGL((normalise_kernel<bf16_t>), dim3(rblocks(n, 2048)), dim3(256), 0, s, labels, n, mean, stdv, (bf16_t*)img_t, img_f32);
+  return check_launch("normalise");
+}
+
+template <typename TI, typename TOo>
+__global__ void convert_kernel(const TI* __restrict__ in, TOo* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    Elem<TOo>::store(out + i, Elem<TI>::load(in + i));
+}
+int launch_convert(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  const dim3 g(rblocks(n, 2048)), b(256);
+  if (dt_in == DT_F32 && dt_out == DT_F32) hipLaunchKernelGGL((convert_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, n);
+  else if (dt_in == DT_F32) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), g, b, 0, s, (const float*)in, (bf16_t*)out, n);
+  else if (dt_out == DT_F32) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)in, (float*)out, n);
+  else hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)in, (bf16_t*)out, n);
+  return check_launch("convert");
+}
+
+// out[r][0..ca) = a[r][:], out[r][ca..ca+cb) = b[r][:]   (f32 -> T); b may be null (cb = 0)
+template <typename T>
+__global__ void concat2_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows, int ca, int cb, T* __restrict__ out) {
+  const long total = (long)rows * (ca + cb);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (ca + cb)), c = (int)(i - (long)r * (ca + cb));
+    const float v = c < ca ? a[(long)r * ca + c] : b[(long)r * cb + (c - ca)];
+    Elem<T>::store(out + i, v);
+  }
+}
+int launch_concat2_to_t(int dt, const float* a, const float* b, int rows, int ca, int cb, void* out, hipStream_t s) {
+  const long total = (long)rows * (ca + cb);
+  if (total <= 0) return MMVAE_OK;
+  if (dt == DT_F32) hipLaunchKernelGGL((concat2_kernel<float>), dim3(rblocks(total)), dim3(256), 0, s, a, b, rows, ca, cb, (float*)out);
+  else hipLaunchKernelGGL((concat2_kernel<bf16_t>), dim3(rblocks(total)), dim3(256), 0, s, a, b, rows, ca, cb, (bf16_t*)out);
+  return check_launch("concat2");
+}
+
+// out = { (nll*px + klc*kl + mmdc*mmd)/N, nll*px/N, kl/N, mmd/N }   (model.py:405-406); acc = {px, kl, mmd}
+__global__ void loss_finish_kernel(const double* acc, float* out, float nll, float klc, float mmdc, float n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double px = (double)nll * acc[0], kl = acc[1], mmd = acc[2];
+    out[0] = (float)((px + (double)klc * kl + (double)mmdc * mmd) / (double)n);
+    out[1] = (float)(px / (double)n);
+    out[2] = (float)(kl / (double)n);
+    out[3] = (float)(mmd / (double)n);
+  }
+}
+int launch_loss_finish(const double* acc, float* out, float nll, float klc, float mmdc, float n, hipStream_t s) {
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, acc, out, nll, klc, mmdc, n);
+  return check_launch("loss_finish");
+}
+
+__global__ void d2f_kernel(const double* in, float* out, int n, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)(in[i] * (double)scale);
+}
+int launch_double_to_float(const double* in, float* out, int n, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(d2f_kernel, dim3((n + 63) / 64), dim3(64), 0, s, in, out, n, scale);
+  return check_launch("d2f");
+}
+
+}  // namespace mmvae

@@ -1,0 +1,455 @@
+#include "vae_net.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "conv_ops.hpp"
+
+namespace mmvae {
+
+#define MM_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ < 0) return rc__;  \
+  } while (0)
+
+static inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+static inline int down_size(int H, int k, int s, int p) { return conv_down_size(H, k, s, p); }
+
+// ------------------------------------------------------------------------------------------------ construction
+void Net::add_entry(const std::string& name, std::initializer_list<int> shape, int kind, long off) {
+  Entry e; e.name = name; e.ndim = (int)shape.size(); e.kind = kind; e.offset = off;
+  int i = 0; for (int d : shape) e.shape[i++] = d;
+  for (; i < 4; ++i) e.shape[i] = 1;
+  entries.push_back(e);
+}
+
+ConvW Net::add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack) {
+  ConvW w; w.off = n_params; w.D0 = D0; w.D1 = D1; w.k = k; w.s = s; w.p = p; w.packD = w.packU = -1;
+  add_entry(name, {D0, D1, k, k}, EK_PARAM, n_params);
+  const long numel = (long)D0 * D1 * k * k;
+  n_params += numel;
+  if (pack) { w.packD = n_packed; n_packed += align_up(numel, 8); w.packU = n_packed; n_packed += align_up(numel, 8); }
+  return w;
+}
+
+Bn Net::add_bn(const std::string& prefix, int C) {
+  Bn b; b.C = C;
+  b.g_off = n_params; add_entry(prefix + ".weight", {C}, EK_PARAM, n_params); n_params += C;
+  b.b_off = n_params; add_entry(prefix + ".bias", {C}, EK_PARAM, n_params); n_params += C;
+  b.rm_off = n_bnbuf; add_entry(prefix + ".running_mean", {C}, EK_BN_F32, n_bnbuf); n_bnbuf += C;
+  b.rv_off = n_bnbuf; add_entry(prefix + ".running_var", {C}, EK_BN_F32, n_bnbuf); n_bnbuf += C;
+  b.nbt_idx = n_nbt; { Entry e; e.name = prefix + ".num_batches_tracked"; e.ndim = 0; e.kind = EK_BN_I64; e.offset = n_nbt;
+                       for (int i = 0; i < 4; ++i) e.shape[i] = 1; entries.push_back(e); } n_nbt += 1;
+  b.ws = n_bnws; n_bnws += 7L * align_up(C, 4);
+  return b;
+}
+
+Net::Net(const NetCfg& c) : cfg(c) {
+  const int S = c.S;
+  // ---- encoder (model.py:89-112)
+  H1 = W1 = down_size(S, 5, 2, 2);
+  stem = add_conv("encoder.conv1.weight", 32, c.in_ch, 5, 2, 2, false);
+  bn0 = add_bn("encoder.bn1", 32);
+  int inpl = 32, H = H1;
+  const int planes[4] = {32, 64, 128, 256};
+  for (int i = 0; i < 4; ++i) {
+    Block& B = enc[i];
+    const std::string p = "encoder.layer" + std::to_string(i + 1) + ".0.";
+    B.Cin = inpl; B.C = planes[i]; B.Hin = B.Win = H; B.Hout = B.Wout = down_size(H, 3, 2, 1); B.Hmid = B.Wmid = B.Hout;
+    B.c1 = add_conv(p + "conv1.weight", planes[i], inpl, 3, 2, 1, true);       // conv3x3 stride 2 (:29,:98-101)
+    B.b1 = add_bn(p + "bn1", planes[i]);
+    B.c2 = add_conv(p + "conv2.weight", planes[i], planes[i], 3, 1, 1, true);  // conv3x3 (:33)
+    B.b2 = add_bn(p + "bn2", planes[i]);
+    B.cs = add_conv(p + "downsample.0.weight", planes[i], inpl, 1, 2, 0, true);  // conv1x1 stride 2 (:135-138)
+    B.bs = add_bn(p + "downsample.1", planes[i]);
+    inpl = planes[i]; H = B.Hout;
+  }
+  Hf = Wf = H;
+  head_mu = add_conv("encoder.conv_mu.weight", c.z, 256, 1, 1, 0, false);
+  if (c.need_logvar) head_lv = add_conv("encoder.conv_logvar.weight", c.z, 256, 1, 1, 0, false);
+  const long hp = align_up((long)c.z * Hf * Wf * 256, 8);
+  head_pack_mu = n_packed; n_packed += hp;
+  head_pack_lv = n_packed; n_packed += hp;
+  head_pack_dg = n_packed; n_packed += align_up(2L * c.z * 256, 8);
+  // ---- decoder (model.py:154-179)
+  dec_param_off = n_params;
+  dstem = add_conv("decoder.conv1.weight", c.z, 128, 2, 2, 0, true);   // k2 s1 p0 on a 1x1 input == k2 s2 p0
+  dbn0 = add_bn("decoder.bn1", 128);
+  nup = S > 32 ? 5 : 4;                                               // :169
+  const int ups[5] = {128, 64, 32, 16, 16};
+  int cin = 128; H = 2;
+  for (int i = 0; i < nup; ++i) {
+    Block& B = dec[i];
+    const std::string p = "decoder.uplayer" + std::to_string(i + 1) + ".0.";
+    B.Cin = cin; B.C = ups[i]; B.Hin = B.Win = H; B.Hmid = B.Wmid = H; B.Hout = B.Wout = 2 * H;
+    B.c1 = add_conv(p + "conv1.weight", ups[i], cin, 1, 1, 0, true);        // 1x1 (:60)
+    B.b1 = add_bn(p + "bn1", ups[i]);
+    B.c2 = add_conv(p + "conv2.weight", ups[i], ups[i], 4, 2, 1, true);      // ConvT k4 s2 p1 (:62-65)
+    B.b2 = add_bn(p + "bn2", ups[i]);
+    B.cs = add_conv(p + "upsample.0.weight", cin, ups[i], 4, 2, 1, true);    // ConvT k4 s2 p1 (:198-201)
+    B.bs = add_bn(p + "upsample.1", ups[i]);
+    cin = ups[i]; H = 2 * H;
+  }
+  Sd = H;
+  tail = add_conv("decoder.conv2.weight", c.out_ch, 16, 3, 1, 1, false);
+  tail_bias = n_params; add_entry("decoder.conv2.bias", {c.out_ch}, EK_PARAM, n_params); n_params += c.out_ch;
+  bn_out = add_bn("decoder.bn2", c.out_ch);
+}
+
+// ------------------------------------------------------------------------------------------------ planning
+size_t Net::workspace_bytes(int N) { return plan(N).bytes; }
+
+const Plan& Net::plan(int N) {
+  if (plan_.N == N) return plan_;
+  Plan P; P.N = N;
+  long cur = 0, maxact = 0;
+  const long e = (long)esz();
+  auto take = [&](long bytes) { long o = cur; cur = align_up(cur + std::max(bytes, 16L), 256); return o; };
+  auto act = [&](long elems) { maxact = std::max(maxact, elems * e); return take(elems * e); };
+  P.x_t = act((long)N * cfg.S * cfg.S);
+  P.y0 = act((long)N * H1 * W1 * 32);
+  for (int i = 0; i < 4; ++i) {
+    Block& B = enc[i];
+    const long n = (long)N * B.Hout * B.Wout * B.C;
+    B.y1 = act(n); B.y2 = act(n); B.ys = act(n); B.out = act(n);
+  }
+  P.enc_t = act((long)N * cfg.z);
+  P.y0d = act((long)N * 4 * 128);
+  for (int i = 0; i < nup; ++i) {
+    Block& B = dec[i];
+    const long n = (long)N * B.Hout * B.Wout * B.C;
+    B.y1 = act((long)N * B.Hin * B.Win * B.C); B.y2 = act(n); B.ys = act(n); B.out = act(n);
+  }
+  P.r_raw = take((long)N * cfg.out_ch * Sd * Sd * 4);
+  P.d_raw = take((long)N * cfg.out_ch * Sd * Sd * 4);
+  P.col = act((long)N * H1 * W1 * 32);
+  P.packed = take(n_packed * e);
+  P.bnws = take(n_bnws * 4);
+  P.partials = take(4096L * 3 * 256 * 4);
+  for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
+  P.dy1 = take(maxact); P.dy2 = take(maxact); P.dys = take(maxact); P.da1 = take(maxact);
+  P.dh = take((long)N * 2 * cfg.z * e);
+  P.bytes = (size_t)cur;
+  plan_ = P;
+  return plan_;
+}
+
+float* Net::bnf(const Bn& bn, char* base, int which) const {
+  return reinterpret_cast<float*>(base + plan_.bnws) + bn.ws + (long)which * align_up(bn.C, 4);
+}
+
+// ------------------------------------------------------------------------------------------------ conv helpers
+static inline ConvGeom geom(const ConvW& w) { return ConvGeom{w.D0, w.D1, w.k, w.s, w.p}; }
+
+int Net::pack_down(const ConvW& w, const float* params, char* base, hipStream_t s) {
+  return op_pack_down(dt(), geom(w), params + w.off, base + plan_.packed + w.packD * (long)esz(), s);
+}
+int Net::pack_up(const ConvW& w, const float* params, char* base, hipStream_t s) {
+  return op_pack_up(dt(), geom(w), params + w.off, base + plan_.packed + w.packU * (long)esz(), s);
+}
+int Net::run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
+                  const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s) {
+  return op_run_down(dt(), out_dt, geom(w), base + plan_.packed + w.packD * (long)esz(), N, L, Hl, Wl, S, Hs, Ws, pro_s, pro_b, relu,
+                     stats, accumulate, s);
+}
+int Net::run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
+                const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s) {
+  return op_run_up(dt(), geom(w), base + plan_.packed + w.packU * (long)esz(), N, S, Hs, Ws, L, Hl, Wl, pro_s, pro_b, relu, stats,
+                   accumulate, s);
+}
+int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
+                   const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s) {
+  return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s);
+}
+
+int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s) {
+  BnFinalizeArgs a;
+  a.partials = reinterpret_cast<const float*>(base + plan_.partials); a.nparts = nparts; a.C = bn.C; a.count = count;
+  a.gamma = params + bn.g_off; a.beta = params + bn.b_off;
+  a.running_mean = bnbuf ? bnbuf + bn.rm_off : nullptr; a.running_var = bnbuf ? bnbuf + bn.rv_off : nullptr;
+  a.nbt = nbt ? nbt + bn.nbt_idx : nullptr;
+  a.mean = bnf(bn, base, 0); a.istd = bnf(bn, base, 1); a.scale = bnf(bn, base, 2); a.shift = bnf(bn, base, 3);
+  a.momentum = 0.1f; a.eps = 1e-5f;
+  return launch_bn_finalize(a, s);
+}
+
+int Net::bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s) {
+  return launch_bn_eval_affine(params + bn.g_off, params + bn.b_off, bnbuf + bn.rm_off, bnbuf + bn.rv_off, 1e-5f, bn.C,
+                               bnf(bn, base, 2), bnf(bn, base, 3), s);
+}
+
+int Net::bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
+                           hipStream_t s) {
+  BnBwdFinalizeArgs a;
+  a.partials = reinterpret_cast<const float*>(base + plan_.partials); a.nparts = nparts; a.C = bn.C; a.which = which; a.ny = ny;
+  a.count = count; a.gamma = params + bn.g_off; a.mean = bnf(bn, base, 0); a.istd = bnf(bn, base, 1);
+  a.dgamma = grads + bn.g_off; a.dbeta = grads + bn.b_off;
+  a.coefA = bnf(bn, base, 4); a.coefB = bnf(bn, base, 5); a.coefC = bnf(bn, base, 6);
+  return launch_bn_bwd_finalize(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------ encoder
+int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
+                     float* mu, float* logvar, int training, hipStream_t s) {
+  if (cfg.in_ch != 1) { set_error("encoder: in_channels=%d unsupported (1)", cfg.in_ch); return MMVAE_ERR_UNSUPPORTED; }
+  if (Hf > 2) { set_error("encoder: image size %d unsupported (final map %dx%d)", cfg.S, Hf, Wf); return MMVAE_ERR_UNSUPPORTED; }
+  const Plan& P = plan(N);
+  if (ws_bytes < P.bytes) { set_error("workspace too small: %zu < %zu", ws_bytes, P.bytes); return MMVAE_ERR_WORKSPACE; }
+  char* base = static_cast<char*>(ws);
+  float* part = reinterpret_cast<float*>(base + P.partials);
+  float* stats = training ? part : nullptr;
+  const int S = cfg.S;
+  MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
+  MM_TRY(launch_stem_fwd(dt(), base + P.x_t, params + stem.off, base + P.y0, N, S, S, H1, W1, 32, s));
+  if (training) {
+    const int np = launch_chan_stats_nhwc(dt(), base + P.y0, (long)N * H1 * W1, 32, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
+  } else {
+    MM_TRY(bn_eval(bn0, params, bnbuf, base, s));
+  }
+  const void* xin = base + P.y0;
+  const float* xs = bnf(bn0, base, 2);
+  const float* xb = bnf(bn0, base, 3);
+  for (int i = 0; i < 4; ++i) {
+    Block& B = enc[i];
+    const double cnt = (double)N * B.Hout * B.Wout;
+    MM_TRY(pack_down(B.c1, params, base, s));
+    MM_TRY(pack_down(B.c2, params, base, s));
+    MM_TRY(pack_down(B.cs, params, base, s));
+    int np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b1, params, bnbuf, base, s));
+    np = run_down(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.bs, params, bnbuf, base, s));
+    np = run_down(B.c2, base, N, base + B.y1, B.Hout, B.Wout, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
+                  stats, 0, dt(), s);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
+    MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2),
+                           bnf(B.bs, base, 3), base + B.out, (long)N * B.Hout * B.Wout, B.C, s));
+    xin = base + B.out; xs = xb = nullptr;
+  }
+  // global average pool + the two 1x1 heads (model.py:123-128) as ONE k=Hf,s=Hf conv whose taps share W/(Hf*Wf)
+  const int nt = Hf * Wf;
+  for (int h = 0; h < (cfg.need_logvar ? 2 : 1); ++h) {
+    const ConvW& hw = h == 0 ? head_mu : head_lv;
+    const long poff = h == 0 ? head_pack_mu : head_pack_lv;
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = params + hw.off; pa.dst = base + P.packed + poff * (long)esz();
+    pa.cols = cfg.z; pa.K = 256; pa.ntaps = nt; pa.s_col = 256; pa.s_k = 1; pa.scale = 1.0f / nt;
+    MM_TRY(launch_pack(dt(), pa, s));
+    GatherArgs a; std::memset(&a, 0, sizeof(a));
+    a.x = xin; a.w = base + P.packed + poff * (long)esz(); a.y = h == 0 ? mu : logvar;
+    a.N = N; a.Hi = Hf; a.Wi = Wf; a.Cin = 256; a.Ho = 1; a.Wo = 1; a.Cout = cfg.z; a.SI = Hf; a.SO = 1;
+    a.nphase = 1; a.phases[0] = Phase{0, 0, 1, 1, nt, 0, 0};
+    for (int kh = 0; kh < Hf; ++kh) for (int kw = 0; kw < Wf; ++kw) a.taps[kh * Wf + kw] = Tap{kh, kw};
+    MM_TRY(launch_gather_gemm(dt(), DT_F32, a, s));
+  }
+  return MMVAE_OK;
+}
+
+int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const float* params, float* grads, void* ws, size_t ws_bytes,
+                     hipStream_t s) {
+  const Plan& P = plan(N);
+  if (ws_bytes < P.bytes) { set_error("workspace too small"); return MMVAE_ERR_WORKSPACE; }
+  char* base = static_cast<char*>(ws);
+  float* part = reinterpret_cast<float*>(base + P.partials);
+  const int Ch = cfg.need_logvar ? 2 * cfg.z : cfg.z;
+  const int nt = Hf * Wf;
+  // ---- heads: dh = [d_mu | d_logvar] in T
+  MM_TRY(launch_concat2_to_t(dt(), d_mu, cfg.need_logvar ? d_logvar : nullptr, N, cfg.z, cfg.need_logvar ? cfg.z : 0, base + P.dh, s));
+  {
+    WgradArgs a; std::memset(&a, 0, sizeof(a));
+    a.P = base + P.dh; a.G = base + enc[3].out; a.dW = grads + head_mu.off; a.proP_relu = a.proG_relu = 0;
+    a.N = N; a.Hp = 1; a.Wp = 1; a.Ca = Ch; a.Hg = Hf; a.Wg = Wf; a.Cb = 256; a.Cb_valid = 256;
+    a.stride = Hf; a.pad = 0; a.ksz = Hf; a.sA = 256; a.sB = 1; a.ntaps = nt; a.scale = 1.0f / nt;
+    MM_TRY(launch_wgrad(dt(), a, s));
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
+    pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / nt;
+    MM_TRY(launch_pack(dt(), pa, s));
+    GatherArgs g; std::memset(&g, 0, sizeof(g));
+    g.x = base + P.dh; g.w = pa.dst; g.y = base + P.g[0];
+    g.N = N; g.Hi = 1; g.Wi = 1; g.Cin = Ch; g.Ho = Hf; g.Wo = Wf; g.Cout = 256; g.SI = 1; g.SO = Hf;
+    g.nphase = nt;
+    for (int i = 0; i < nt; ++i) { g.phases[i] = Phase{i / Wf, i % Wf, 1, 1, 1, i, 0}; g.taps[i] = Tap{0, 0}; }
+    MM_TRY(launch_gather_gemm(dt(), dt(), g, s));
+  }
+  int cur = 0;   // d_out lives in g[cur]
+  for (int i = 3; i >= 0; --i) {
+    Block& B = enc[i];
+    const long npix = (long)N * B.Hout * B.Wout;
+    const double cnt = (double)npix;
+    const void* xin = i == 0 ? base + P.y0 : base + enc[i - 1].out;
+    const float* xs = i == 0 ? bnf(bn0, base, 2) : nullptr;
+    const float* xb = i == 0 ? bnf(bn0, base, 3) : nullptr;
+    // join backward: g = d_out * [out > 0] feeds bn2 (y2) and the shortcut BN (ys)
+    int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, base + B.ys, npix, B.C, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, cnt, s));
+    MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, cnt, s));
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
+                               bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
+                               base + P.dys, npix, B.C, s));
+    // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
+    MM_TRY(run_wgrad(B.c2, N, base + P.dy2, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
+                     bnf(B.b1, base, 3), grads, s));
+    MM_TRY(pack_up(B.c2, params, base, s));
+    MM_TRY(run_up(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
+    // bn1 + relu backward
+    np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, cnt, s));
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),
+                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix,
+                               B.C, s));
+    // conv1 (3x3 s2) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
+    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
+    MM_TRY(run_wgrad(B.cs, N, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
+    MM_TRY(pack_up(B.c1, params, base, s));
+    MM_TRY(pack_up(B.cs, params, base, s));
+    MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
+    MM_TRY(run_up(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
+    cur ^= 1;
+  }
+  // ---- stem: bn0 + relu backward, then the 5x5 weight gradient through an im2col of the 1-channel image
+  {
+    const long npix = (long)N * H1 * W1;
+    int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, nullptr, npix, 32, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_backward_coefs(bn0, params, grads, base, np, 1, 0, (double)npix, s));
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, bnf(bn0, base, 4),
+                               bnf(bn0, base, 5), bnf(bn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 32, s));
+    MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, s));
+    WgradArgs a; std::memset(&a, 0, sizeof(a));
+    a.P = base + P.dy1; a.G = base + P.col; a.dW = grads + stem.off;
+    a.N = N; a.Hp = H1; a.Wp = W1; a.Ca = 32; a.Hg = H1; a.Wg = W1; a.Cb = 32; a.Cb_valid = 25;
+    a.stride = 1; a.pad = 0; a.ksz = 1; a.sA = 25; a.sB = 1; a.ntaps = 1; a.scale = 1.f;
+    MM_TRY(launch_wgrad(dt(), a, s));
+  }
+  return MMVAE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
+                     float* recon, int training, hipStream_t s) {
+  const Plan& P = plan(N);
+  if (ws_bytes < P.bytes) { set_error("workspace too small: %zu < %zu", ws_bytes, P.bytes); return MMVAE_ERR_WORKSPACE; }
+  char* base = static_cast<char*>(ws);
+  float* part = reinterpret_cast<float*>(base + P.partials);
+  float* stats = training ? part : nullptr;
+  MM_TRY(launch_convert(DT_F32, dt(), encv, base + P.enc_t, (long)N * cfg.z, s));
+  // stem ConvTranspose2d(z -> 128, k2) on the 1x1 latent (model.py:159-161,182)
+  MM_TRY(pack_up(dstem, params, base, s));
+  int np = run_up(dstem, base, N, base + P.enc_t, 1, 1, base + P.y0d, 2, 2, nullptr, nullptr, 0, stats, 0, s);
+  MM_TRY(np);
+  MM_TRY(training ? bn_train(dbn0, params, bnbuf, nbt, base, np, (double)N * 4, s) : bn_eval(dbn0, params, bnbuf, base, s));
+  const void* xin = base + P.y0d;
+  const float* xs = bnf(dbn0, base, 2);
+  const float* xb = bnf(dbn0, base, 3);
+  for (int i = 0; i < nup; ++i) {
+    Block& B = dec[i];
+    MM_TRY(pack_down(B.c1, params, base, s));
+    MM_TRY(pack_up(B.c2, params, base, s));
+    MM_TRY(pack_up(B.cs, params, base, s));
+    np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hin, B.Win, xs, xb, 1, stats, 0, dt(), s);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, (double)N * B.Hin * B.Win, s) : bn_eval(B.b1, params, bnbuf, base, s));
+    const double cnt = (double)N * B.Hout * B.Wout;
+    np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
+    np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats, 0, s);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.bs, params, bnbuf, base, s));
+    MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2),
+                           bnf(B.bs, base, 3), base + B.out, (long)N * B.Hout * B.Wout, B.C, s));
+    xin = base + B.out; xs = xb = nullptr;
+  }
+  // tail conv (+bias) and the output BatchNorm (model.py:193)
+  float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
+  MM_TRY(launch_tail_fwd(dt(), xin, params + tail.off, params + tail_bias, r_raw, N, Sd, Sd, cfg.out_ch, s));
+  if (training) {
+    np = launch_chan_stats_nchw(r_raw, N, cfg.out_ch, Sd * Sd, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
+  } else {
+    MM_TRY(bn_eval(bn_out, params, bnbuf, base, s));
+  }
+  MM_TRY(launch_affine_nchw(r_raw, bnf(bn_out, base, 2), bnf(bn_out, base, 3), recon, N, cfg.out_ch, Sd * Sd, s));
+  return MMVAE_OK;
+}
+
+int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* grads, void* ws, size_t ws_bytes, float* d_enc,
+                     hipStream_t s) {
+  const Plan& P = plan(N);
+  if (ws_bytes < P.bytes) { set_error("workspace too small"); return MMVAE_ERR_WORKSPACE; }
+  char* base = static_cast<char*>(ws);
+  float* part = reinterpret_cast<float*>(base + P.partials);
+  float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
+  float* d_raw = reinterpret_cast<float*>(base + P.d_raw);
+  const int HW = Sd * Sd;
+  // ---- output BN backward, tail conv backward
+  int np = launch_bn_bwd_reduce_nchw(d_recon, r_raw, N, cfg.out_ch, HW, part, s);
+  MM_TRY(np);
+  MM_TRY(bn_backward_coefs(bn_out, params, grads, base, np, 1, 0, (double)N * HW, s));
+  MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
+  MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, grads + tail_bias, N, Sd, Sd, cfg.out_ch, s));
+  int cur = 0;
+  MM_TRY(launch_tail_dgrad(dt(), d_raw, params + tail.off, base + P.g[cur], N, Sd, Sd, cfg.out_ch, s));
+  for (int i = nup - 1; i >= 0; --i) {
+    Block& B = dec[i];
+    const long npo = (long)N * B.Hout * B.Wout, npi = (long)N * B.Hin * B.Win;
+    const void* xin = i == 0 ? base + P.y0d : base + dec[i - 1].out;
+    const float* xs = i == 0 ? bnf(dbn0, base, 2) : nullptr;
+    const float* xb = i == 0 ? bnf(dbn0, base, 3) : nullptr;
+    np = launch_bn_bwd_reduce(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, base + B.ys, npo, B.C, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
+    MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, (double)npo, s));
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
+                               bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
+                               base + P.dys, npo, B.C, s));
+    // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
+    MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2, B.Hout, B.Wout, nullptr,
+                     nullptr, grads, s));
+    MM_TRY(pack_down(B.c2, params, base, s));
+    MM_TRY(run_down(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
+    np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, (double)npi, s));
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),
+                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npi,
+                               B.C, s));
+    // conv1 (1x1): wgrad(P = dy1, G = xin); upsample (ConvT): wgrad(P = xin, G = dys)
+    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
+    MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, grads, s));
+    // d_xin = dgrad(conv1)(dy1) + dgrad(upsample)(dys)
+    MM_TRY(pack_up(B.c1, params, base, s));
+    MM_TRY(pack_down(B.cs, params, base, s));
+    MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
+    MM_TRY(run_down(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, dt(), s));
+    cur ^= 1;
+  }
+  // ---- decoder stem
+  {
+    const long npix = (long)N * 4;
+    np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(dbn0, base, 2), bnf(dbn0, base, 3), base + P.y0d, nullptr, npix, 128, part, s);
+    MM_TRY(np);
+    MM_TRY(bn_backward_coefs(dbn0, params, grads, base, np, 1, 0, (double)npix, s));
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(dbn0, base, 2), bnf(dbn0, base, 3), base + P.y0d, bnf(dbn0, base, 4),
+                               bnf(dbn0, base, 5), bnf(dbn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 128, s));
+    MM_TRY(run_wgrad(dstem, N, base + P.enc_t, 1, 1, nullptr, nullptr, base + P.dy1, 2, 2, nullptr, nullptr, grads, s));
+    if (d_enc) {
+      MM_TRY(pack_down(dstem, params, base, s));
+      MM_TRY(run_down(dstem, base, N, base + P.dy1, 2, 2, base + P.dh, 1, 1, nullptr, nullptr, 0, nullptr, 0, dt(), s));
+      MM_TRY(launch_convert(dt(), DT_F32, base + P.dh, d_enc, (long)N * cfg.z, s));
+    }
+  }
+  return MMVAE_OK;
+}
+
+}  // namespace mmvae

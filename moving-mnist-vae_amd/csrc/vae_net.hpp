@@ -1,0 +1,94 @@
+// Network-level orchestration of the conv-VAE hot path (encoder / decoder forward + backward).
+// Mirrors the layer structure of the reference model.py (VAE_Encoder :88-150, VAE_Decoder :153-209,
+// BasicBlock :23-55, DeconvBottleneck :57-85) but owns no tensors: parameters, BN buffers, gradients and
+// the activation workspace are caller-provided device pointers.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace mmvae {
+
+struct NetCfg { int in_ch, z, out_ch, S, need_logvar, dtype; };
+
+enum EntryKind : int { EK_PARAM = 0, EK_BN_F32 = 1, EK_BN_I64 = 2 };
+struct Entry { std::string name; int ndim; int shape[4]; int kind; long offset; };
+
+// A conv-like weight [D0][D1][k][k] relating a "small" tensor S [N,Hs,Ws,D0] and a "large" tensor L [N,Hl,Wl,D1],
+// Hs = floor((Hl + 2p - k)/s) + 1.  Conv2d: weight (out,in,k,k), forward = down(L->S).  ConvTranspose2d: weight
+// (in,out,k,k), forward = up(S->L).
+struct ConvW { long off; int D0, D1, k, s, p; long packD, packU; };
+struct Bn { long g_off, b_off, rm_off, rv_off; int nbt_idx; int C; long ws; /* float offset of this BN's 7*C scratch */ };
+
+struct Block {   // encoder BasicBlock or decoder DeconvBottleneck (both: main c1->c2, shortcut cs, join)
+  ConvW c1, c2, cs; Bn b1, b2, bs;
+  int Cin, C, Hin, Win, Hmid, Wmid, Hout, Wout;
+  long y1, y2, ys, out;   // byte offsets in the workspace
+};
+
+struct Plan {
+  int N = -1;
+  size_t bytes = 0;
+  long x_t, y0, enc_t, y0d, r_raw, d_raw, col;           // byte offsets
+  long packed;                                           // packed weights (T)
+  long bnws;                                             // float scratch for all BNs
+  long partials;                                         // reduction partials (floats)
+  long g[2], dy1, dy2, dys, da1, dh;                     // backward temporaries
+  long enc_ws_end;
+};
+
+class Net {
+ public:
+  explicit Net(const NetCfg& c);
+  NetCfg cfg;
+  std::vector<Entry> entries;
+  long n_params = 0, n_bnbuf = 0; int n_nbt = 0;
+  long dec_param_off = 0;            // first decoder parameter (flat f32 index)
+  long n_packed = 0;                 // packed weight elements
+  long n_bnws = 0;                   // floats of BN scratch
+  int H1, W1, Hf, Wf, Sd, nup;
+  // layers
+  ConvW stem; Bn bn0;
+  Block enc[4];
+  ConvW head_mu, head_lv; long head_pack_mu, head_pack_lv, head_pack_dg;
+  ConvW dstem; Bn dbn0;
+  Block dec[5];
+  ConvW tail; long tail_bias; Bn bn_out;
+
+  size_t workspace_bytes(int N);
+  const Plan& plan(int N);
+
+  int encoder_fwd(int N, const float* x, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
+                  float* mu, float* logvar, int training, hipStream_t s);
+  int encoder_bwd(int N, const float* d_mu, const float* d_logvar, const float* params, float* grads, void* ws, size_t ws_bytes,
+                  hipStream_t s);
+  int decoder_fwd(int N, const float* enc, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
+                  float* recon, int training, hipStream_t s);
+  int decoder_bwd(int N, const float* d_recon, const float* params, float* grads, void* ws, size_t ws_bytes, float* d_enc,
+                  hipStream_t s);
+
+ private:
+  Plan plan_;
+  int dt() const { return cfg.dtype; }
+  size_t esz() const { return dtype_size(cfg.dtype); }
+  ConvW add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack);
+  Bn add_bn(const std::string& prefix, int C);
+  void add_entry(const std::string& name, std::initializer_list<int> shape, int kind, long off);
+
+  int pack_down(const ConvW& w, const float* params, char* base, hipStream_t s);
+  int pack_up(const ConvW& w, const float* params, char* base, hipStream_t s);
+  int run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
+               const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s);
+  int run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
+             const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s);
+  int run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
+                const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s);
+  int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s);
+  int bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s);
+  float* bnf(const Bn& bn, char* base, int which) const;   // 0 mean 1 istd 2 scale 3 shift 4 A 5 B 6 C
+  int bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
+                        hipStream_t s);
+};
+
+}  // namespace mmvae

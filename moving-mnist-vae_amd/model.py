@@ -1,0 +1,620 @@
+"""Drop-in ``VAE`` for the reference ``model.VAE`` (model.py:258-439), MI355X-native.
+
+Same constructor keywords, attributes, ``forward`` / ``loss`` / helper signatures, ``state_dict`` keys and
+parameter registration order as the reference; every arithmetic op of the hot path runs in hand-written HIP
+kernels behind the C ABI of ``include/mmvae.h``.  PyTorch is used for device memory, the ``nn.Module`` /
+autograd shell and ``torch.distributed`` only.  There is NO CPU fallback: without the built library, or
+without a GPU, the model raises.
+
+Layout: all parameters live in ONE flat f32 device buffer (``nn.Parameter``s are views into it, in the
+reference's registration order), likewise gradients, Adam moments and BN running statistics -- so the
+optimiser step is one kernel and the data-parallel all-reduce is two bucket-sized collectives.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import weakref
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from ._lib import MmvaeError, check, lib, ptr
+
+_DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Scope(nn.Module):
+    """Name-space node of the module tree (mirrors the reference's nesting so state_dict keys match)."""
+
+    def __init__(self, owner=None, role=None):
+        super().__init__()
+        self.__dict__["_owner_ref"] = weakref.ref(owner) if owner is not None else None
+        self.__dict__["_role"] = role
+
+    def forward(self, *a, **k):  # encoder(x) / decoder(z), like VAE_Encoder / VAE_Decoder (model.py:114,181)
+        owner = self._owner_ref() if self._owner_ref else None
+        if owner is None or self._role is None:
+            raise MmvaeError("this sub-module is a parameter name-space; call the VAE instead")
+        return owner._encode(*a, **k) if self._role == "encoder" else owner._decode_full(*a, **k)
+
+    def rsample(self, mu, logvar):   # VAE_Encoder.rsample, model.py:148-150
+        owner = self._owner_ref() if self._owner_ref else None
+        if owner is None or self._role != "encoder":
+            raise AttributeError("rsample")
+        return owner._rsample(mu, logvar)
+
+
+# ------------------------------------------------------------------------------------------ autograd glue
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        N = x.shape[0]
+        z = model.z_dimensions
+        mu = torch.empty((N, z, 1, 1), device=x.device, dtype=torch.float32)
+        logvar = torch.empty_like(mu) if model.require_rsample else None
+        training = bool(model.training)
+        ws = model._workspace(N, training)
+        check(lib().mmvae_encoder_fwd(model._h, N, ptr(x), ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
+                                      ptr(mu), ptr(logvar), int(training), _stream()), "mmvae_encoder_fwd")
+        ctx.model, ctx.N, ctx.training = model, N, training
+        ctx.token = model._stamp("enc", training)
+        if logvar is None:
+            return mu
+        return mu, logvar
+
+    @staticmethod
+    def backward(ctx, d_mu, d_logvar=None):
+        model = ctx.model
+        model._check_stamp("enc", ctx.token, ctx.training)
+        z, N = model.z_dimensions, ctx.N
+        dev = model._flat.device
+        d_mu = torch.zeros((N, z), device=dev) if d_mu is None else d_mu.contiguous().float()
+        if model.require_rsample:
+            d_logvar = torch.zeros((N, z), device=dev) if d_logvar is None else d_logvar.contiguous().float()
+        G = model._grad_target()
+        G[:model._dec_off].zero_()
+        ws = model._workspace(N, True)
+        check(lib().mmvae_encoder_bwd(model._h, N, ptr(d_mu), ptr(d_logvar), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), _stream()),
+              "mmvae_encoder_bwd")
+        if model._sync is not None:
+            model._sync.bucket_ready(G, 0, model._dec_off)
+        return (None, None) + model._grad_views(G, 0)
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, encoding, *params):
+        N = encoding.shape[0]
+        training = bool(model.training)
+        recon = torch.empty((N, model.decoder_out_channels, model._dec_side, model._dec_side), device=encoding.device,
+                            dtype=torch.float32)
+        ws = model._workspace(N, training)
+        check(lib().mmvae_decoder_fwd(model._h, N, ptr(encoding), ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
+                                      ptr(recon), int(training), _stream()), "mmvae_decoder_fwd")
+        ctx.model, ctx.N, ctx.training = model, N, training
+        ctx.token = model._stamp("dec", training)
+        ctx.need_denc = bool(ctx.needs_input_grad[1])
+        return recon
+
+    @staticmethod
+    def backward(ctx, d_recon):
+        model = ctx.model
+        model._check_stamp("dec", ctx.token, ctx.training)
+        N = ctx.N
+        d_recon = d_recon.contiguous().float()
+        d_enc = torch.empty((N, model.z_dimensions, 1, 1), device=d_recon.device, dtype=torch.float32) if ctx.need_denc else None
+        G = model._grad_target()
+        G[model._dec_off:].zero_()
+        ws = model._workspace(N, True)
+        check(lib().mmvae_decoder_bwd(model._h, N, ptr(d_recon), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), ptr(d_enc), _stream()),
+              "mmvae_decoder_bwd")
+        if model._sync is not None:
+            model._sync.bucket_ready(G, model._dec_off, model._n_params)
+        return (None, d_enc) + model._grad_views(G, 1)
+
+
+class _RsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        enc = torch.empty_like(mu)
+        check(lib().mmvae_rsample_fwd(ptr(mu), ptr(logvar), ptr(eps), ptr(enc), mu.numel(), _stream()), "mmvae_rsample_fwd")
+        ctx.save_for_backward(logvar, eps)
+        return enc
+
+    @staticmethod
+    def backward(ctx, d_enc):
+        logvar, eps = ctx.saved_tensors
+        d_enc = d_enc.contiguous()
+        d_mu, d_lv = torch.empty_like(d_enc), torch.empty_like(d_enc)
+        check(lib().mmvae_rsample_bwd(ptr(d_enc), ptr(logvar), ptr(eps), ptr(d_mu), ptr(d_lv), d_enc.numel(), _stream()), "mmvae_rsample_bwd")
+        return d_mu, d_lv, None
+
+
+class _LossFn(torch.autograd.Function):
+    """VAE.loss arithmetic (model.py:385-405): KL + MMD + Gaussian-NLL | weighted CE, all reductions on device."""
+
+    @staticmethod
+    def forward(ctx, model, target, mu, logvar, encoding, recon, true_samples, weight):
+        L = lib()
+        N = target.shape[0]
+        dev = recon.device
+        acc = torch.zeros(4, dtype=torch.float64, device=dev)      # px, kl, mmd
+        out = torch.empty(4, dtype=torch.float32, device=dev)      # loss, px/N, kl/N, mmd/N
+        st = _stream()
+        base = acc.data_ptr()
+        recon = recon.contiguous()
+        categorical = model.decoder_out_channels > model.in_channels
+        if mu is not None and logvar is not None:
+            mu, logvar = mu.contiguous(), logvar.contiguous()
+            check(L.mmvae_kl_fwd(ptr(mu), ptr(logvar), mu.numel(), base + 8, st), "mmvae_kl_fwd")
+        if encoding is not None:
+            encoding = encoding.contiguous()
+            check(L.mmvae_mmd_fwd(ptr(true_samples), ptr(encoding), N, encoding.shape[1], base + 16, st), "mmvae_mmd_fwd")
+        if categorical:
+            target = target.contiguous()
+            Q, HW = recon.shape[1], recon.shape[2] * recon.shape[3]
+            check(L.mmvae_ce_fwd(ptr(recon), ptr(target), ptr(weight), N, Q, HW, base, st), "mmvae_ce_fwd")
+        else:
+            target = target.contiguous()
+            check(L.mmvae_gauss_nll_fwd(ptr(recon), ptr(target), recon.numel(), float(model.sigma_decoder), base, st), "mmvae_gauss_nll_fwd")
+        check(L.mmvae_loss_finish(base, ptr(out), float(model.nll), float(model.kl), float(model.mmd), float(N), st), "mmvae_loss_finish")
+        model._last_scalars = out
+        ctx.model, ctx.N, ctx.categorical = model, N, categorical
+        ctx.save_for_backward(target, mu, logvar, encoding, recon, true_samples, weight)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = lib()
+        model, N = ctx.model, ctx.N
+        target, mu, logvar, encoding, recon, ts, weight = ctx.saved_tensors
+        st = _stream()
+        g = g.contiguous().float()
+        d_recon = torch.empty_like(recon)
+        if ctx.categorical:
+            Q, HW = recon.shape[1], recon.shape[2] * recon.shape[3]
+            check(L.mmvae_ce_bwd(ptr(recon), ptr(target), ptr(weight), N, Q, HW, float(model.nll) / N, ptr(g), ptr(d_recon), st), "mmvae_ce_bwd")
+        else:
+            check(L.mmvae_gauss_nll_bwd(ptr(recon), ptr(target), recon.numel(), float(model.sigma_decoder), float(model.nll) / N, ptr(g),
+                                        ptr(d_recon), st), "mmvae_gauss_nll_bwd")
+        d_mu = d_lv = d_enc = None
+        if mu is not None and logvar is not None:
+            d_mu, d_lv = torch.empty_like(mu), torch.empty_like(logvar)
+            check(L.mmvae_kl_bwd(ptr(mu), ptr(logvar), float(model.kl) / N, ptr(g), ptr(d_mu), ptr(d_lv), mu.numel(), st), "mmvae_kl_bwd")
+        if encoding is not None and float(model.mmd) != 0.0:
+            d_enc = torch.zeros_like(encoding)
+            check(L.mmvae_mmd_bwd(ptr(ts), ptr(encoding), N, encoding.shape[1], float(model.mmd) / N, ptr(g), ptr(d_enc), st), "mmvae_mmd_bwd")
+        return None, None, d_mu, d_lv, d_enc, d_recon, None, None
+
+
+# ------------------------------------------------------------------------------------------ the model
+class VAE(nn.Module):
+    def __init__(self, in_channels, intermediate_channels, decoder_out_channels=1, pixelcnn_out_channels=2,
+                 z_dimension=32,
+                 pixelcnn=True, only_pixelcnn=True, pixelcnn_layers=4, pixelcnn_activation="ReLu", nll=1, kl=1, mmd=0,
+                 require_rsample=True, sigma_decoder=0.1, input_image_size=64, compute_dtype=None):
+        """Same arguments as the reference (model.py:259-262) plus ``compute_dtype`` ("bf16" default, or "f32";
+        also settable through the MMVAE_DTYPE environment variable): storage type of activations / MFMA inputs."""
+        super().__init__()
+        if pixelcnn or only_pixelcnn:
+            raise NotImplementedError("only the plain conv-VAE path (pixelcnn=False, only_pixelcnn=False) is built; "
+                                      "PixelCNN / PixelVAE models are out of scope (SURVEY.md section 8f)")
+        self.in_channels = in_channels
+        self.z_dimensions = z_dimension
+        self.decoder_out_channels = decoder_out_channels
+        self.pixelcnn_out_channels = pixelcnn_out_channels
+        self.num_pixelcnn_layers = pixelcnn_layers
+        self.require_rsample = require_rsample
+        self.nll, self.kl, self.mmd = nll, kl, mmd
+        self.sigma_decoder = sigma_decoder
+        self.input_image_size = input_image_size
+        self.only_pixelcnn = only_pixelcnn
+        self.pixelcnn = None
+        self.adjust = (64 - input_image_size) // 2 if input_image_size > 32 else (32 - input_image_size) // 2   # model.py:307-310
+        dt = compute_dtype or os.environ.get("MMVAE_DTYPE", "bf16")
+        if dt not in _DTYPES:
+            raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
+        self.compute_dtype = "f32" if _DTYPES[dt] == 0 else "bf16"
+
+        L = lib()
+        h = ctypes.c_void_p()
+        check(L.mmvae_net_create(ctypes.byref(h), in_channels, z_dimension, decoder_out_channels, input_image_size,
+                                 int(bool(require_rsample)), _DTYPES[dt]), "mmvae_net_create")
+        self.__dict__["_h"] = h
+        n_params, n_bnf, dec_off = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        n_bni, dec_side = ctypes.c_int32(), ctypes.c_int32()
+        check(L.mmvae_net_sizes(h, ctypes.byref(n_params), ctypes.byref(n_bnf), ctypes.byref(n_bni), ctypes.byref(dec_off),
+                                ctypes.byref(dec_side)), "mmvae_net_sizes")
+        d = self.__dict__
+        d["_n_params"], d["_n_bnf"], d["_n_bni"] = n_params.value, n_bnf.value, n_bni.value
+        d["_dec_off"], d["_dec_side"] = dec_off.value, dec_side.value
+        d["_flat"] = torch.zeros(self._n_params, dtype=torch.float32)
+        d["_bnf"] = torch.zeros(self._n_bnf, dtype=torch.float32)
+        d["_bni"] = torch.zeros(self._n_bni, dtype=torch.int64)
+        d["_G"] = [None, None]
+        d["_ws"] = {True: None, False: None}
+        d["_stamps"] = {}
+        d["_sync"] = None
+        d["_last_scalars"] = None
+        d["injected_eps"] = None           # parity tests: noise for rsample / loss instead of torch.randn
+        d["injected_true_samples"] = None
+        d["_ptable"], d["_btable"] = [], []
+        self._build_tree(L)
+        self._reset_parameters()
+
+    # ---- construction helpers
+    def _build_tree(self, L):
+        name_buf = ctypes.create_string_buffer(128)
+        ndim, kind = ctypes.c_int32(), ctypes.c_int32()
+        shape = (ctypes.c_int32 * 4)()
+        off = ctypes.c_int64()
+        for i in range(L.mmvae_net_num_entries(self._h)):
+            check(L.mmvae_net_entry(self._h, i, name_buf, 128, ctypes.byref(ndim), shape, ctypes.byref(kind), ctypes.byref(off)), "mmvae_net_entry")
+            name = name_buf.value.decode()
+            shp = tuple(shape[k] for k in range(ndim.value))
+            numel = 1
+            for s in shp:
+                numel *= s
+            parts = name.split(".")
+            node = self
+            for depth, comp in enumerate(parts[:-1]):
+                if comp not in node._modules:
+                    role = comp if (depth == 0 and comp in ("encoder", "decoder")) else None
+                    node.add_module(comp, _Scope(self, role))
+                node = node._modules[comp]
+            if kind.value == 0:
+                p = nn.Parameter(self._flat[off.value:off.value + numel].view(shp))
+                p._mmvae_owner = weakref.ref(self)
+                node.register_parameter(parts[-1], p)
+                self._ptable.append((name, p, off.value, numel, shp))
+            elif kind.value == 1:
+                node.register_buffer(parts[-1], self._bnf[off.value:off.value + numel].view(shp))
+                self._btable.append((node, parts[-1], 1, off.value, numel, shp))
+            else:
+                node.register_buffer(parts[-1], self._bni[off.value:off.value + 1].view(()))
+                self._btable.append((node, parts[-1], 2, off.value, 1, ()))
+        self.__dict__["_enc_params"] = [p for (_, p, o, _, _) in self._ptable if o < self._dec_off]
+        self.__dict__["_dec_params"] = [p for (_, p, o, _, _) in self._ptable if o >= self._dec_off]
+
+    @torch.no_grad()
+    def _reset_parameters(self):
+        """PyTorch default initialisation in the reference's module-construction order, so that
+        ``torch.manual_seed(s); VAE(...)`` yields the same parameters as the reference under the same seed:
+        convs kaiming_uniform(a=sqrt(5)), conv bias U(+-1/sqrt(fan_in)), BN gamma=1 beta=0, running stats (0,1).
+        Order: a block's shortcut conv is created before its main-path convs (model.py:132-141, :196-207)."""
+        byname = {n: p for (n, p, _, _, _) in self._ptable}
+
+        def conv(name):
+            nn.init.kaiming_uniform_(byname[name], a=math.sqrt(5))
+
+        conv("encoder.conv1.weight")
+        for i in range(1, 5):
+            pre = f"encoder.layer{i}.0."
+            conv(pre + "downsample.0.weight"); conv(pre + "conv1.weight"); conv(pre + "conv2.weight")
+        conv("encoder.conv_mu.weight")
+        if self.require_rsample:
+            conv("encoder.conv_logvar.weight")
+        conv("decoder.conv1.weight")
+        i = 1
+        while f"decoder.uplayer{i}.0.conv1.weight" in byname:
+            pre = f"decoder.uplayer{i}.0."
+            conv(pre + "upsample.0.weight"); conv(pre + "conv1.weight"); conv(pre + "conv2.weight")
+            i += 1
+        conv("decoder.conv2.weight")
+        w = byname["decoder.conv2.weight"]
+        bound = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
+        nn.init.uniform_(byname["decoder.conv2.bias"], -bound, bound)
+        for (name, p, _, _, shp) in self._ptable:
+            if len(shp) == 1 and name != "decoder.conv2.bias":
+                p.fill_(1.0 if name.endswith(".weight") else 0.0)
+        for (node, leaf, k, _, _, _) in self._btable:
+            b = node._buffers[leaf]
+            if leaf == "running_var":
+                b.fill_(1.0)
+            else:
+                b.zero_()
+
+    # ---- flat storage management
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._reflatten()
+        return self
+
+    @torch.no_grad()
+    def _reflatten(self):
+        dev = self._ptable[0][1].device
+        flat = torch.empty(self._n_params, dtype=torch.float32, device=dev)
+        for (_, p, off, n, shp) in self._ptable:
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(shp)
+            p.grad = None
+        bnf = torch.empty(self._n_bnf, dtype=torch.float32, device=dev)
+        bni = torch.empty(self._n_bni, dtype=torch.int64, device=dev)
+        for (node, leaf, k, off, n, shp) in self._btable:
+            src = node._buffers[leaf]
+            if k == 1:
+                bnf[off:off + n].copy_(src.reshape(-1))
+                node._buffers[leaf] = bnf[off:off + n].view(shp)
+            else:
+                bni[off:off + 1].copy_(src.reshape(-1))
+                node._buffers[leaf] = bni[off:off + 1].view(())
+        d = self.__dict__
+        d["_flat"], d["_bnf"], d["_bni"] = flat, bnf, bni
+        d["_G"] = [None, None]
+        d["_ws"] = {True: None, False: None}
+
+    def _ensure_flat(self):
+        first, last = self._ptable[0], self._ptable[-1]
+        base, es = self._flat.data_ptr(), 4
+        if first[1].data_ptr() != base + first[2] * es or last[1].data_ptr() != base + last[2] * es:
+            self._reflatten()
+        if not self._flat.is_cuda:
+            raise MmvaeError("the HIP VAE only runs on a GPU: call model.to('cuda') first (there is no CPU fallback; "
+                             "the CPU restatement under oracle/ is test infrastructure)")
+
+    def _workspace(self, N, training):
+        need = lib().mmvae_net_workspace_bytes(self._h, int(N))
+        ws = self._ws[training]
+        if ws is None or ws.numel() < need or ws.device != self._flat.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=self._flat.device)
+            self._ws[training] = ws
+        return ws
+
+    def _stamp(self, which, training):
+        tok = self._stamps.get((which, training), 0) + 1
+        self._stamps[(which, training)] = tok
+        return tok
+
+    def _check_stamp(self, which, tok, training):
+        if not training:
+            raise MmvaeError("backward through an eval-mode forward is not supported (BatchNorm batch statistics are needed)")
+        if self._stamps.get((which, training)) != tok:
+            raise MmvaeError("the saved activations of this forward were overwritten by a later forward; "
+                             "call backward before running the model again in train mode")
+
+    def _grad_target(self):
+        """Flat gradient buffer to write into: buffer 0 normally; buffer 1 when .grad tensors already exist
+        (so that autograd's accumulation into them stays correct)."""
+        p0 = self._ptable[0][1]
+        idx = 0
+        if p0.grad is not None and self._G[0] is not None and p0.grad.data_ptr() == self._G[0].data_ptr():
+            idx = 1
+        if self._G[idx] is None or self._G[idx].device != self._flat.device:
+            self._G[idx] = torch.zeros(self._n_params, dtype=torch.float32, device=self._flat.device)
+        return self._G[idx]
+
+    def _grad_views(self, G, part):
+        tab = [e for e in self._ptable if (e[2] < self._dec_off) == (part == 0)]
+        lo = tab[0][2]
+        hi = tab[-1][2] + tab[-1][3]
+        chunks = G[lo:hi].split([e[3] for e in tab])
+        return tuple(c.view(e[4]) for c, e in zip(chunks, tab))
+
+    # ---- the reference surface
+    def _encode(self, x):
+        self._ensure_flat()
+        x = x.contiguous().float()
+        S = self.input_image_size
+        if x.dim() != 4 or x.shape[1] != self.in_channels or x.shape[2] != S or x.shape[3] != S:
+            raise ValueError(f"expected input (N,{self.in_channels},{S},{S}), got {tuple(x.shape)}")
+        out = _EncoderFn.apply(self, x, *self._enc_params)
+        return out if self.require_rsample else (out, None)
+
+    def _rsample(self, mu, logvar):
+        eps = self.injected_eps
+        if eps is None:
+            eps = torch.randn(mu.shape, device=mu.device, dtype=mu.dtype)
+        return _RsampleFn.apply(mu, logvar, eps.to(mu.device).view(mu.shape))
+
+    def _decode_full(self, encoding):
+        self._ensure_flat()
+        enc = encoding.contiguous().float().view(-1, self.z_dimensions, 1, 1)
+        return _DecoderFn.apply(self, enc, *self._dec_params)
+
+    def _decode(self, encoding):
+        out = self._decode_full(encoding)
+        if self.adjust != 0:                                   # model.py:328-329
+            out = out[:, :, self.adjust:-self.adjust, self.adjust:-self.adjust]
+        return out
+
+    def forward(self, x, sample=None):
+        """model.py:316-342 (pixelcnn=None): returns (mu, logvar, encoding, reconstruction)."""
+        mu, logvar = self._encode(x)
+        encoding = self._rsample(mu, logvar) if self.require_rsample else mu
+        return mu, logvar, encoding, self._decode(encoding)
+
+    def get_z_image(self, encoding):                           # model.py:344-348
+        return self._decode(encoding)
+
+    def get_reconstruction(self, encoding, sample=None):       # model.py:353-362
+        return self._decode(encoding)
+
+    def run_pixelcnn(self, concat):                            # model.py:350-351
+        raise NotImplementedError("PixelCNN is out of scope")
+
+    def kl_divergence(self, encoding_mu, encoding_logvar):     # model.py:364-365
+        acc = torch.zeros(1, dtype=torch.float64, device=encoding_mu.device)
+        mu, lv = encoding_mu.contiguous().float(), encoding_logvar.contiguous().float()
+        check(lib().mmvae_kl_fwd(ptr(mu), ptr(lv), mu.numel(), ptr(acc), _stream()), "mmvae_kl_fwd")
+        return acc[0].float()
+
+    def compute_mmd(self, x, y):                               # model.py:378-383
+        acc = torch.zeros(1, dtype=torch.float64, device=x.device)
+        x, y = x.contiguous().float(), y.contiguous().float()
+        check(lib().mmvae_mmd_fwd(ptr(x), ptr(y), x.shape[0], x.shape[1], ptr(acc), _stream()), "mmvae_mmd_fwd")
+        return acc[0].float()
+
+    def loss(self, target, encoding_mu, encoding_logvar, encoding, reconstruction, device, args):
+        """model.py:385-406: returns (loss tensor with grad, nll/N, kl/N, mmd/N as Python floats).
+        One device->host copy of the four scalars instead of the reference's three ``.item()`` calls."""
+        N = target.shape[0]
+        dev = reconstruction.device
+        categorical = self.decoder_out_channels > self.in_channels
+        ts = None
+        enc2 = None
+        if encoding is not None:
+            enc2 = encoding.view(-1, encoding.shape[1])
+            ts = self.injected_true_samples
+            if ts is None:
+                ts = torch.randn(N, encoding.shape[1], device=dev)          # model.py:395
+            ts = ts.to(dev).contiguous().float()
+        weight = None
+        if categorical:
+            weight = getattr(args, "data_ratio_of_labels", None)
+            if weight is not None:
+                weight = weight.to(dev).contiguous().float()
+            if target.dtype != torch.int64:
+                target = target.long()
+        loss_t = _LossFn.apply(self, target, encoding_mu, encoding_logvar, enc2, reconstruction, ts, weight)
+        vals = self._last_scalars.tolist()
+        return loss_t, vals[1], vals[2], vals[3]
+
+    # ---- train-loop hook (main.py:374-388): labels -> normalised frames, one kernel
+    def prepare_batch(self, batch, device, data_mean, data_std, categorical):
+        S = self.input_image_size
+        labels = batch.to(device)
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        labels = labels.contiguous()
+        image = torch.empty((labels.numel() // (S * S), 1, S, S), device=labels.device, dtype=torch.float32)
+        check(lib().mmvae_normalise_labels(ptr(labels), labels.numel(), float(data_mean), float(data_std), ptr(image), _stream()),
+              "mmvae_normalise_labels")
+        target = labels.view(-1, S, S) if categorical else image
+        return image, target
+
+    def __repr__(self):
+        s = (f"VAE[MI355X/HIP, {self.compute_dtype}]: encoder {self.input_image_size}x{self.input_image_size}x{self.in_channels}"
+             f" -> z={self.z_dimensions}" + (" (Gaussian reparameterisation)" if self.require_rsample else "") +
+             f" -> decoder {self.input_image_size}x{self.input_image_size}x{self.decoder_out_channels}; ")
+        if self.decoder_out_channels == self.in_channels:
+            s += f"p(x|z) = Normal(recon, sigma={self.sigma_decoder})"
+        else:
+            s += "p(x|z) categorical"
+        return s + f"; loss = {self.nll}*nll + {self.kl}*kl + {self.mmd}*mmd"
+
+    def __del__(self):
+        try:
+            h = self.__dict__.get("_h")
+            if h:
+                lib().mmvae_net_destroy(h)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (defaults of main.py:468) as ONE HIP kernel over the model's flat parameter buffer.
+    Drop-in: ``FusedAdam(list(model.parameters()))``; ``state_dict()`` has the torch.optim.Adam layout."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        owner = getattr(params[0], "_mmvae_owner", None)
+        model = owner() if owner is not None else None
+        if model is None or [id(p) for p in params] != [id(e[1]) for e in model._ptable]:
+            raise MmvaeError("FusedAdam needs exactly list(model.parameters()) of one HIP VAE, in order")
+        self._model = weakref.ref(model)
+        self._t = 0
+        self._m = self._v = None
+
+    def _moments(self, model):
+        flat = model._flat
+        if self._m is None or self._m.device != flat.device:
+            old_m, old_v = self._m, self._v
+            self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+            if old_m is not None:
+                self._m.copy_(old_m); self._v.copy_(old_v)
+            for (_, p, off, n, shp) in model._ptable:
+                self.state[p] = {"step": torch.tensor(float(self._t)), "exp_avg": self._m[off:off + n].view(shp),
+                                 "exp_avg_sq": self._v[off:off + n].view(shp)}
+        return self._m, self._v
+
+    def _flat_grads(self, model):
+        first, last = model._ptable[0][1], model._ptable[-1][1]
+        if first.grad is None:
+            return None
+        for G in model._G:
+            if G is not None and first.grad.data_ptr() == G.data_ptr() and last.grad is not None and \
+                    last.grad.data_ptr() == G.data_ptr() + model._ptable[-1][2] * 4:
+                return G
+        G = model._grad_target()                     # slow path: gradients live elsewhere -> gather
+        for (_, p, off, n, _) in model._ptable:
+            if p.grad is None:
+                G[off:off + n].zero_()
+            else:
+                G[off:off + n].copy_(p.grad.reshape(-1))
+        return G
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        model = self._model()
+        model._ensure_flat()
+        G = self._flat_grads(model)
+        if G is None:
+            return loss
+        scale = 1.0
+        if model._sync is not None:
+            scale = model._sync.finish(G)
+        g = self.param_groups[0]
+        m, v = self._moments(model)
+        self._t += 1
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** self._t
+        bc2s = math.sqrt(1.0 - b2 ** self._t)
+        check(lib().mmvae_adam_step(ptr(model._flat), ptr(G), ptr(m), ptr(v), model._n_params, float(g["lr"]), float(b1), float(b2),
+                                    float(g["eps"]), float(g["weight_decay"]), bc1, bc2s, scale, _stream()), "mmvae_adam_step")
+        for st in self.state.values():
+            st["step"] = torch.tensor(float(self._t))
+        return loss
+
+
+# ------------------------------------------------------------------------------------------ data parallel
+class GradSync:
+    """Data-parallel gradient exchange: one process per GPU, sum-all-reduce (RCCL over xGMI via
+    torch.distributed's "nccl" backend) of the flat gradient in two buckets -- decoder gradients are complete
+    first and are reduced while the encoder backward still runs -- and 1/world scaling folded into Adam.
+    BatchNorm statistics stay per-rank (like DistributedDataParallel's default)."""
+
+    def __init__(self, model, group=None, broadcast=True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.handles = []
+        self.reduced = []
+        model._sync = self
+        if broadcast and self.world > 1:
+            model._ensure_flat() if model._flat.is_cuda else None
+            dist.broadcast(model._flat, 0, group=group)
+            dist.broadcast(model._bnf, 0, group=group)
+
+    def bucket_ready(self, G, lo, hi):
+        if self.world == 1:
+            return
+        self.handles.append(self.dist.all_reduce(G[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.reduced.append((lo, hi))
+
+    def finish(self, G):
+        """Wait for the in-flight buckets; returns the factor Adam applies to the summed gradient."""
+        for h in self.handles:
+            h.wait()
+        covered = sorted(self.reduced)
+        self.handles, self.reduced = [], []
+        if self.world > 1:
+            pos = 0
+            for lo, hi in covered:
+                if lo > pos:
+                    self.dist.all_reduce(G[pos:lo], op=self.dist.ReduceOp.SUM, group=self.group)
+                pos = max(pos, hi)
+            if pos < G.numel():
+                self.dist.all_reduce(G[pos:], op=self.dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / self.world
