@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: conv-VAE train step (encoder -> reparameterise -> decoder -> ELBO -> backward -> Adam)
+on synthetic 20x64x64 Moving-MNIST clips (BASELINE.json configs[1]: 256 clips = 5120 frames per GPU, z=128, bf16).
+
+  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of this repo's ``train`` loop body (main.py:371-399 restated) over one batch that is already
+resident in HBM: labels -> normalise -> forward -> loss -> zero_grad -> backward -> FusedAdam.step, including the one
+host read-back of the four scalars per step.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "moving-mnist-vae_amd"
+METRIC = "frames/sec/GPU VAE train step, 20×64×64 batch; ELBO vs CPU ref"
+DATA_MEAN, DATA_STD, P_ON = 0.0521, 0.2222, 0.0521
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+TRAIN_BYTES_PER_FRAME = 3.40e6  # ideal-fusion bf16 activation traffic of one train step, per frame
+TRAIN_FLOP_PER_FRAME = 227409920  # z=128, SURVEY.md section 8(d)
+
+
+def synthetic_clips(clips, seed, device):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    lab = (torch.rand((clips, 20, 64, 64), generator=g) < P_ON).long()
+    return lab.to(device)
+
+
+def cpu_baseline(clips, steps, z):
+    """The oracle (bit-identical restatement of the reference model.py) timed on this host's cores with
+    torch.optim.Adam, on a bounded sample of the same workload."""
+    from oracle import vae_oracle as O
+    pkg = importlib.import_module(PKG)
+    torch.manual_seed(0)
+    m = O.OracleVAE(1, 32, 1, 2, z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64)
+    m.tiled_mmd = True
+    opt = torch.optim.Adam(list(m.parameters()))
+    args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
+    batch = synthetic_clips(clips, 1234, "cpu")
+    pkg.train(m, [batch], opt, torch.device("cpu"), args, data_mean=DATA_MEAN, data_std=DATA_STD)   # warm-up
+    t0 = time.perf_counter()
+    pkg.train(m, [batch] * steps, opt, torch.device("cpu"), args, data_mean=DATA_MEAN, data_std=DATA_STD)
+    dt = time.perf_counter() - t0
+    frames = clips * 20 * steps
+    return {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} train steps of {clips} clips x 20 frames (z={z}, fp32, torch CPU ops, tiled MMD), oracle/vae_oracle.py",
+            "ms_per_step": 1e3 * dt / steps}
+
+
+def elbo_check(M, device, dtype):
+    """Small live parity sample: ELBO of the HIP model vs the CPU oracle on the same weights / inputs / noise."""
+    from oracle import vae_oracle as O
+    N, z = 40, 128
+    spec = O.state_spec(1, z, 1, 64, True)
+    torch.manual_seed(0)
+    m = M.VAE(1, 32, 1, 2, z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype=dtype)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.to(device).train()
+    labels = O.synthetic_labels(N, 64, seed=3)
+    image = O.normalise(labels, 64)
+    eps, ts = torch.randn(N, z, 1, 1), torch.randn(N, z)
+    mu, lv, enc, rec = O.vae_forward({k: v.clone() for k, v in state.items()}, image, eps, 64, True, True)
+    ref = O.vae_loss(image, mu, lv, enc, rec, ts, nll=1, kl=1, mmd=0, sigma_decoder=0.1)[0].item()
+    m.injected_eps, m.injected_true_samples = eps.to(device), ts.to(device)
+    with torch.no_grad():
+        hmu, hlv, henc, hrec = m(image.to(device))
+        got = m.loss(image.to(device), hmu, hlv, henc, hrec, device, types.SimpleNamespace())[0].item()
+    return abs(got - ref) / abs(ref)
+
+
+def dominant_kernel_roofline(M, device, N, reps=20):
+    """HBM roofline of the dominant kernel class, measured live with events on the launch stream: the gather-form
+    implicit-GEMM at the decoder's widest layer (decoder.uplayer5.0.conv2, ConvTranspose2d 16->16 k4 s2, 32^2 -> 64^2).
+    Algorithmic bytes per launch = input + output activations (bf16) + weights, each touched once."""
+    L = importlib.import_module(PKG + "._lib")
+    lib = L.lib()
+    Cin = Cout = 16
+    H = 32
+    x = torch.randn(N, H, H, Cin, device=device).to(torch.bfloat16)
+    w = torch.randn(Cin, Cout, 4, 4, device=device) * 0.1
+    y = torch.empty(N, 2 * H, 2 * H, Cout, device=device, dtype=torch.bfloat16)
+    scratch = torch.empty(2 * w.numel() * 2 + 256, dtype=torch.uint8, device=device)
+    stats = torch.zeros(4096 * 2 * Cout, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        L.check(lib.mmvae_conv2d_fwd(1, 1, L.ptr(x), L.ptr(w), L.ptr(y), N, H, H, Cin, Cout, 4, 2, 1, None, None, 0, L.ptr(stats),
+                                     L.ptr(scratch), st), "conv2d_fwd")
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = x.numel() * 2 + y.numel() * 2 + w.numel() * 2
+    ach = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "gather_gemm_kernel<bf16,bf16,1> @ decoder.uplayer5.0.conv2 (4 stride-phases in one launch, + weight pack)",
+            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--clips", type=int, default=256, help="clips (of 20 frames) per GPU per step")
+    ap.add_argument("--z", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    pkg = importlib.import_module(PKG)
+    M = importlib.import_module(PKG + ".model")
+
+    torch.manual_seed(0)                      # identical initial weights on every rank (and broadcast below)
+    model = M.VAE(1, 32, 1, 2, a.z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype=a.dtype).to(device).train()
+    opt = M.FusedAdam(list(model.parameters()))
+    if world > 1:
+        M.GradSync(model)
+    args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
+    batch = synthetic_clips(a.clips, 1234 + rank, device)
+    frames = a.clips * 20
+
+    def run(k):
+        return pkg.train(model, [batch] * k, opt, device, args, data_mean=DATA_MEAN, data_std=DATA_STD)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        run(a.warmup)
+    fence()
+    t0 = time.perf_counter()
+    losses = run(a.steps)[0]
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    if rank == 0:
+        value = world * frames * a.steps / dt
+        out = {
+            "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {a.clips} clips x 20 frames x 64x64 per GPU per step (={frames} frames), "
+                                   f"conv-VAE z={a.z}, Gaussian NLL sigma=0.1 + KL (normal_vae_1_kl_0_mmd), Adam, "
+                                   f"random-init weights, Bernoulli({P_ON}) q=2 labels",
+                       "global_frames_per_step": world * frames, "parallelism": f"dp{world}", "bn": "per-rank batch statistics"},
+            "frames_per_sec_per_gpu": value / world,
+            "final_loss": losses[-1],
+            "step_hbm_roofline": {"algorithmic_bytes_per_frame": TRAIN_BYTES_PER_FRAME, "achieved_GBs": value / world * TRAIN_BYTES_PER_FRAME / 1e9,
+                                  "frac_of_8TBs": value / world * TRAIN_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS,
+                                  "mfma_frac_of_2.5PF": value / world * TRAIN_FLOP_PER_FRAME / 2.5e15},
+        }
+        if not a.no_roofline:
+            out["roofline"] = dominant_kernel_roofline(M, device, frames)
+            out["elbo_rel_err_vs_cpu_oracle"] = elbo_check(M, device, a.dtype)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(32, 3, a.z)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,9 @@
 //
 // Both stage 128-byte K-rows (8 x 16-byte "kvecs") through LDS with an XOR swizzle and feed
 // v_mfma_f32_16x16x32_bf16 (bf16 storage) or v_mfma_f32_16x16x4_f32 (exact f32 mode).
+#include <stdlib.h>
+#include <string.h>
+
 #include "kernels.hpp"
 
 namespace mmvae {
@@ -246,6 +249,62 @@ static int launch_gather_t(GatherArgs& a, int gx, hipStream_t s) {
   return rc ? rc : gx * a.nphase;
 }
 
+bool conv_force_v1() {
+  static const int v = [] { const char* e = getenv("MMVAE_CONV_V1"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+
+bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w) {
+  if (Hq <= 0 || Wq <= 0 || Wq > 128 || N <= 0) return false;
+  g.N = N; g.Hq = Hq; g.Wq = Wq; g.Hi = Hi; g.Wi = Wi; g.SI = SI; g.oh = oh; g.ow = ow;
+  if (Hq * Wq >= 128) {
+    g.segs = 1; g.qr = 128 / Wq; if (g.qr > Hq) g.qr = Hq;
+    g.tiles_per_img = (Hq + g.qr - 1) / g.qr;
+    g.ntiles = N * g.tiles_per_img;
+  } else {
+    g.segs = 128 / (Hq * Wq); g.qr = Hq; g.tiles_per_img = 0;
+    g.ntiles = (N + g.segs - 1) / g.segs;
+  }
+  g.PR = (g.qr - 1) * SI + span_h;
+  g.PW = (Wq - 1) * SI + span_w;
+  return true;
+}
+
+constexpr size_t kV2MaxLds = 60 * 1024;
+
+// Returns >0 (stats rows) when the v2 kernel ran, 0 when the launch is not eligible, <0 on error.
+static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
+  if (conv_force_v1() || a.Cout > 64 || a.Cin > 512) return 0;
+  Gather2Args b; memset(&b, 0, sizeof(b));
+  b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
+  b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate;
+  b.Cin = a.Cin; b.Cout = a.Cout; b.Ho = a.Ho; b.Wo = a.Wo; b.SO = a.SO; b.nphase = a.nphase;
+  int max_tiles = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    const Phase& ph = a.phases[p];
+    int dh0 = 0, dh1 = 0, dw0 = 0, dw1 = 0;
+    for (int t = 0; t < ph.ntaps; ++t) {
+      const Tap tp = a.taps[ph.tap0 + t];
+      if (t == 0) { dh0 = dh1 = tp.dh; dw0 = dw1 = tp.dw; }
+      dh0 = tp.dh < dh0 ? tp.dh : dh0; dh1 = tp.dh > dh1 ? tp.dh : dh1;
+      dw0 = tp.dw < dw0 ? tp.dw : dw0; dw1 = tp.dw > dw1 ? tp.dw : dw1;
+    }
+    Phase2& q = b.phases[p];
+    if (!make_tile_geom(q.g, a.N, ph.Hq, ph.Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1)) return 0;
+    q.ph = ph.ph; q.pw = ph.pw; q.ntaps = ph.ntaps; q.tap0 = ph.tap0; q.w_off = ph.w_off;
+    if (q.g.ntiles > max_tiles) max_tiles = q.g.ntiles;
+  }
+  for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
+  const int CT = ((a.Cout + 15) / 16 == 3 ? 4 : (a.Cout + 15) / 16) * 16;
+  const size_t lds = gather2_lds_bytes(b, dt, CT);
+  if (lds > kV2MaxLds) return 0;
+  int occ = (int)((160 * 1024) / lds); if (occ > 4) occ = 4; if (occ < 1) occ = 1;
+  int gx = (256 * occ) / a.nphase; if (gx < 1) gx = 1;
+  if (gx > max_tiles) gx = max_tiles;
+  if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
+  return launch_gather2(dt, out_dt, b, gx, s);
+}
+
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
   if (a.Cin % VE != 0 || a.Cout % 4 != 0 || a.nphase < 1 || a.nphase > kMaxPhases) {
@@ -264,6 +323,10 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   }
   if (ntap > kMaxTaps) { set_error("gather_gemm: %d taps > %d", ntap, kMaxTaps); return MMVAE_ERR_UNSUPPORTED; }
   if (max_tiles <= 0) return 1;
+  {
+    const int rc2 = try_gather2(dt, out_dt, a, s);
+    if (rc2 != 0) return rc2;      // >0: launched (stats rows), <0: error, 0: not eligible -> generic kernel
+  }
   const int gx = max_tiles < kGatherMaxGridX ? max_tiles : kGatherMaxGridX;
   if (dt == DT_F32) return launch_gather_t<float, float>(a, gx, s);
   if (out_dt == DT_F32) return launch_gather_t<bf16_t, float>(a, gx, s);
@@ -425,6 +488,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// Returns 1 when the v2 kernel ran, 0 when not eligible, <0 on error.
+static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
+  if (conv_force_v1() || a.Ca % 16 || a.Cb % 16 || a.ntaps > 16) return 0;
+  auto pick = [](int c) { return c >= 64 ? 64 : c; };
+  const int TA = pick(a.Ca), TB = pick(a.Cb);
+  if (!(TA == 16 || TA == 32 || TA == 64) || !(TB == 16 || TB == 32 || TB == 64)) return 0;
+  if (a.Ca % TA || a.Cb % TB) return 0;
+  const int ta16 = TA / 16, tb16 = TB / 16;
+  Wgrad2Args b; memset(&b, 0, sizeof(b));
+  b.P = a.P; b.G = a.G; b.dW = a.dW;
+  b.proP_scale = a.proP_scale; b.proP_shift = a.proP_shift; b.proP_relu = a.proP_relu;
+  b.proG_scale = a.proG_scale; b.proG_shift = a.proG_shift; b.proG_relu = a.proG_relu;
+  if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz)) return 0;
+  b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
+  int maxtg = 48 / (ta16 * tb16); if (maxtg > 16) maxtg = 16;
+  b.TG = a.ntaps < maxtg ? a.ntaps : maxtg;
+  b.sA = a.sA; b.sB = a.sB; b.scale = a.scale;
+  for (int t = 0; t < 25; ++t) b.tap_off[t] = a.tap_off[t];
+  if (wgrad2_lds_bytes(b, dt, TA, TB) > kV2MaxLds) return 0;
+  const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
+  const int zg = (a.ntaps + b.TG - 1) / b.TG;
+  int gx = 1024 / (tiles_ab * zg); if (gx < 1) gx = 1;
+  if (gx > b.g.ntiles) gx = b.g.ntiles;
+  const int rc = launch_wgrad2(dt, b, gx, tiles_ab, zg, ta16, tb16, s);
+  return rc < 0 ? rc : 1;
+}
+
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
   if (a.Ca % VE != 0 || a.Cb % VE != 0 || a.ntaps > 25 || a.ntaps < 1) {
@@ -434,6 +524,10 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   a.M = a.N * a.Hp * a.Wp;
   if (a.Cb_valid <= 0 || a.Cb_valid > a.Cb) a.Cb_valid = a.Cb;
   if (a.M <= 0) return MMVAE_OK;
+  {
+    const int rc2 = try_wgrad2(dt, a, s);
+    if (rc2 != 0) return rc2 < 0 ? rc2 : MMVAE_OK;
+  }
   const int TA = a.Ca >= 64 ? 64 : ((a.Ca + 15) / 16) * 16;
   const int TB = a.Cb >= 64 ? 64 : ((a.Cb + 15) / 16) * 16;
   a.TA16 = TA / 16; a.TB16 = TB / 16;
@@ -448,6 +542,12 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   const int PK = KV * VE;
   const long ksteps = ((long)a.M + PK - 1) / PK;
   long want = 1024 / ((long)tiles * zg);               // pixel chunks so that ~1024 blocks exist
+  {                                                    // ...but keep the scattered global atomics below ~4M per launch
+    const long wsize = (long)a.Ca * a.Cb * a.ntaps;
+    long cap = (4L << 20) / (wsize > 0 ? wsize : 1);
+    if (cap < 2) cap = 2;
+    if (want > cap) want = cap;
+  }
   if (want < 1) want = 1;
   if (want > ksteps) want = ksteps;
   long steps_per = (ksteps + want - 1) / want;

@@ -1,0 +1,482 @@
+// "Patch-tile" convolution kernels (v2) for the pixel-heavy, small-channel layers that dominate HBM traffic.
+//
+// A tile = up to 128 output-grid ("q") pixels: either `qr` consecutive q-rows of one image, or several whole
+// images.  The input patch every tap of the tile touches is staged in LDS ONCE, in natural NHWC layout
+// (16-byte vector writes, zero-filled padding, optional fused BN+ReLU), and MFMA fragments are gathered from it
+// with per-lane LDS addresses:
+//   * gather2_kernel  (Conv2d fwd / ConvT fwd / dgrads): B fragment = 8 consecutive channels of one tap
+//     -> ds_read_b128 at patch(pixel) + tap offset.  The phase's whole weight matrix sits in LDS for the block's
+//     lifetime (persistent tile loop), so HBM sees each input and output element once.
+//   * wgrad2_kernel   (weight gradients): the reduction runs over pixels, so both operands need pixel-major
+//     fragments; they come from the SAME natural-layout LDS images through ds_read_b64_tr_b16 (hardware
+//     transpose, bf16) or plain ds_read_b32 (f32 mode).  Every tap reuses the staged patch by adding a constant
+//     byte offset.  Accumulators live in registers across the persistent loop; the flush goes through LDS so
+//     that global float atomics are issued on consecutive addresses (256 B per wave instruction).
+#include "kernels.hpp"
+
+namespace mmvae {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ f32x4 mma_bf16(const Vec16& a, const Vec16& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma_f32v(const Vec16& a, const Vec16& b, f32x4 c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w[j]), __uint_as_float(b.w[j]), c, 0, 0, 0);
+  return c;
+}
+template <typename T> __device__ __forceinline__ f32x4 mma_vec(const Vec16& a, const Vec16& b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mma_vec<bf16_t>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_bf16(a, b, c); }
+template <> __device__ __forceinline__ f32x4 mma_vec<float>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_f32v(a, b, c); }
+
+__device__ __forceinline__ void tile_origin(const TileGeom& g, int tile, int seg, int& n, int& hq0) {
+  if (g.tiles_per_img > 0) {
+    n = tile / g.tiles_per_img;
+    hq0 = (tile - n * g.tiles_per_img) * g.qr;
+  } else {
+    n = tile * g.segs + seg;
+    hq0 = 0;
+  }
+}
+
+// patch pixel index (origin-relative, in pixels) of tile pixel p; p must be < segs*qr*Wq
+__device__ __forceinline__ int patch_index(const TileGeom& g, int p) {
+  const int per_seg = g.qr * g.Wq;
+  const int seg = p / per_seg, rem = p - seg * per_seg;
+  const int j = rem / g.Wq, wq = rem - j * g.Wq;
+  return (seg * g.PR + j * g.SI) * g.PW + wq * g.SI;
+}
+
+// Stage the patch of `Cs` channels [c0, c0+Cs) of X (tensor channels C) into LDS: layout [segs*PR][PW][Cs].
+template <typename T>
+__device__ __forceinline__ void stage_patch(const TileGeom& g, int tile, const T* __restrict__ X, int C, int c0, int Cs,
+                                            const float* sPro, int relu, Vec16* sPatch) {
+  constexpr int VE = Elem<T>::kVec;
+  const int cvec = Cs / VE;
+  const int rowvecs = g.PW * cvec;
+  const int total = g.segs * g.PR * rowvecs;
+  for (int v = threadIdx.x; v < total; v += blockDim.x) {
+    const int row = v / rowvecs, rv = v - row * rowvecs;
+    const int pc = rv / cvec, cv = rv - pc * cvec;
+    const int seg = row / g.PR, pr = row - seg * g.PR;
+    int n, hq0;
+    tile_origin(g, tile, seg, n, hq0);
+    const int hi = hq0 * g.SI + g.oh + pr, wi = g.ow + pc;
+    Vec16 q = Vec16{{0, 0, 0, 0}};
+    if (n < g.N && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) {
+      q = *reinterpret_cast<const Vec16*>(X + ((long)(n * g.Hi + hi) * g.Wi + wi) * C + c0 + cv * VE);
+      if (sPro) {
+        float f[VE];
+        Elem<T>::unpack(q, f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          const float x = f[j] * sPro[cv * VE + j] + sPro[512 + cv * VE + j];
+          f[j] = relu ? fmaxf(x, 0.f) : x;
+        }
+        q = Elem<T>::pack(f);
+      }
+    }
+    sPatch[v] = q;
+  }
+}
+
+template <typename TO> __device__ __forceinline__ void store4v(TO* p, const float* v, bool acc);
+template <> __device__ __forceinline__ void store4v<float>(float* p, const float* v, bool acc) {
+  float4 o = make_float4(v[0], v[1], v[2], v[3]);
+  if (acc) { const float4 e = *reinterpret_cast<const float4*>(p); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+  *reinterpret_cast<float4*>(p) = o;
+}
+template <> __device__ __forceinline__ void store4v<bf16_t>(bf16_t* p, const float* v, bool acc) {
+  float f[4] = {v[0], v[1], v[2], v[3]};
+  if (acc) {
+    const uint2 e = *reinterpret_cast<const uint2*>(p);
+    f[0] += __uint_as_float(e.x << 16); f[1] += __uint_as_float(e.x & 0xffff0000u);
+    f[2] += __uint_as_float(e.y << 16); f[3] += __uint_as_float(e.y & 0xffff0000u);
+  }
+  uint2 o;
+  o.x = (uint32_t)f32_to_bf16_bits(f[0]) | ((uint32_t)f32_to_bf16_bits(f[1]) << 16);
+  o.y = (uint32_t)f32_to_bf16_bits(f[2]) | ((uint32_t)f32_to_bf16_bits(f[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = o;
+}
+
+// ============================================================================ gather2
+// LDS carve: [weights: Cout rows x (kvp+1) vec][patch][sKoff: kvp ints][sPro: 1024 floats][sStat: 8*CT floats]
+template <typename T, typename TO, int CT16>
+__global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int ES = sizeof(T);
+  constexpr int CT = CT16 * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Phase2 P = a.phases[blockIdx.z];
+  const TileGeom g = P.g;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, r = lane & 15;
+  const int cin_vecs = a.Cin / VE;
+  const int kvecs = P.ntaps * cin_vecs;
+  const int kvp = (kvecs + 3) & ~3;
+  const int wrow = kvp + 1;                       // weight row stride in vec16 (pad 16 B against bank conflicts)
+  Vec16* sW = reinterpret_cast<Vec16*>(smem);
+  Vec16* sPatch = sW + CT * wrow;
+  const int patch_vecs = g.segs * g.PR * g.PW * cin_vecs;
+  int* sKoff = reinterpret_cast<int*>(sPatch + patch_vecs);
+  float* sPro = reinterpret_cast<float*>(sKoff + kvp);
+  float* sStat = sPro + 1024;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ Wt = reinterpret_cast<const T*>(a.w) + P.w_off;
+  TO* __restrict__ Y = reinterpret_cast<TO*>(a.y);
+  const bool has_pro = a.pro_scale != nullptr;
+  // ---- block prologue: weights, k-offset table, prologue constants
+  for (int v = t; v < CT * kvp; v += 256) {
+    const int row = v / kvp, kv = v - row * kvp;
+    sW[row * wrow + kv] = (kv < kvecs && row < a.Cout) ? *reinterpret_cast<const Vec16*>(Wt + ((long)row * kvecs + kv) * VE) : Vec16{{0, 0, 0, 0}};
+  }
+  for (int v = t; v < kvp; v += 256) {
+    int off = 0;
+    if (v < kvecs) {
+      const int tap = v / cin_vecs, cv = v - tap * cin_vecs;
+      const Tap tp = a.taps[P.tap0 + tap];
+      off = (((tp.dh - g.oh) * g.PW + (tp.dw - g.ow)) * a.Cin + cv * VE) * ES;
+    }
+    sKoff[v] = off;
+  }
+  if (has_pro) for (int i = t; i < a.Cin; i += 256) { sPro[i] = a.pro_scale[i]; sPro[512 + i] = a.pro_shift[i]; }
+  float st1[CT16][4], st2[CT16][4];
+#pragma unroll
+  for (int c = 0; c < CT16; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st1[c][j] = 0.f; st2[c][j] = 0.f; }
+  const int npix_tile = g.segs * g.qr * g.Wq;
+  const int nks = kvp >> 2;
+  const char* patch_bytes = reinterpret_cast<const char*>(sPatch);
+
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    __syncthreads();                 // previous tile's fragment reads are done (also orders the block prologue)
+    stage_patch<T>(g, tile, X, a.Cin, 0, a.Cin, has_pro ? sPro : nullptr, a.pro_relu, sPatch);
+    __syncthreads();
+    int pbase[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      int p = 32 * wv + 16 * pt + r;
+      if (p >= npix_tile) p = 0;
+      pbase[pt] = patch_index(g, p) * a.Cin * ES;
+    }
+    f32x4 acc[CT16][2];
+#pragma unroll
+    for (int c = 0; c < CT16; ++c) { acc[c][0] = (f32x4){0, 0, 0, 0}; acc[c][1] = (f32x4){0, 0, 0, 0}; }
+    for (int ks = 0; ks < nks; ++ks) {
+      const int kv = 4 * ks + gq;
+      const int koff = sKoff[kv];
+      const Vec16 b0 = *reinterpret_cast<const Vec16*>(patch_bytes + pbase[0] + koff);
+      const Vec16 b1 = *reinterpret_cast<const Vec16*>(patch_bytes + pbase[1] + koff);
+#pragma unroll
+      for (int c = 0; c < CT16; ++c) {
+        const Vec16 af = sW[(16 * c + r) * wrow + kv];
+        acc[c][0] = mma_vec<T>(af, b0, acc[c][0]);
+        acc[c][1] = mma_vec<T>(af, b1, acc[c][1]);
+      }
+    }
+    // ---- epilogue: lane holds couts 16c + 4gq + j of pixel 32wv + 16pt + r
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int p = 32 * wv + 16 * pt + r;
+      if (p < npix_tile) {
+        const int per_seg = g.qr * g.Wq;
+        const int seg = p / per_seg, rem = p - seg * per_seg;
+        const int j = rem / g.Wq, wq = rem - j * g.Wq;
+        int n, hq0;
+        tile_origin(g, tile, seg, n, hq0);
+        const int hq = hq0 + j;
+        if (n < g.N && hq < g.Hq) {
+          const long obase = ((long)(n * a.Ho + hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw)) * a.Cout;
+#pragma unroll
+          for (int c = 0; c < CT16; ++c) {
+            const int co = 16 * c + 4 * gq;
+            if (co < a.Cout) {
+              float v[4];
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                v[jj] = acc[c][pt][jj] + (a.bias ? a.bias[co + jj] : 0.f);
+                st1[c][jj] += v[jj];
+                st2[c][jj] += v[jj] * v[jj];
+              }
+              store4v<TO>(Y + obase + co, v, a.accumulate != 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int c = 0; c < CT16; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          st1[c][j] += __shfl_xor(st1[c][j], o, 64);
+          st2[c][j] += __shfl_xor(st2[c][j], o, 64);
+        }
+      }
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+      for (int c = 0; c < CT16; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sStat[wv * 2 * CT + 16 * c + 4 * gq + j] = st1[c][j];
+          sStat[wv * 2 * CT + CT + 16 * c + 4 * gq + j] = st2[c][j];
+        }
+    }
+    __syncthreads();
+    if (t < 2 * CT) {
+      const float s = sStat[t] + sStat[2 * CT + t] + sStat[4 * CT + t] + sStat[6 * CT + t];
+      const int which = t / CT, cl = t - which * CT;
+      if (cl < a.Cout) a.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * a.Cout + (long)which * a.Cout + cl] = s;
+    }
+  }
+}
+
+size_t gather2_lds_bytes(const Gather2Args& a, int dt, int CT) {
+  const int VE = dt == DT_F32 ? 4 : 8;
+  const int cin_vecs = a.Cin / VE;
+  size_t worst = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    const TileGeom& g = a.phases[p].g;
+    const int kvecs = a.phases[p].ntaps * cin_vecs, kvp = (kvecs + 3) & ~3;
+    const size_t b = (size_t)CT * (kvp + 1) * 16 + (size_t)g.segs * g.PR * g.PW * cin_vecs * 16 + (size_t)kvp * 4 + 1024 * 4 + (size_t)8 * CT * 4;
+    if (b > worst) worst = b;
+  }
+  return worst;
+}
+
+template <typename T, typename TO>
+static int launch_gather2_t(const Gather2Args& a, int dt, int gx, hipStream_t s) {
+  int ct16 = (a.Cout + 15) / 16;
+  if (ct16 == 3) ct16 = 4;
+  const size_t lds = gather2_lds_bytes(a, dt, ct16 * 16);
+  dim3 grid(gx, 1, a.nphase), block(256);
+  switch (ct16) {
+    case 1: hipLaunchKernelGGL((gather2_kernel<T, TO, 1>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((gather2_kernel<T, TO, 2>), grid, block, lds, s, a); break;
+    case 3: case 4: hipLaunchKernelGGL((gather2_kernel<T, TO, 4>), grid, block, lds, s, a); break;
+    default: set_error("gather2: Cout=%d too large", a.Cout); return MMVAE_ERR_UNSUPPORTED;
+  }
+  int rc = check_launch("gather2");
+  return rc ? rc : gx * a.nphase;
+}
+
+int launch_gather2(int dt, int out_dt, const Gather2Args& a, int gx, hipStream_t s) {
+  if (dt == DT_F32) return launch_gather2_t<float, float>(a, dt, gx, s);
+  if (out_dt == DT_F32) return launch_gather2_t<bf16_t, float>(a, dt, gx, s);
+  return launch_gather2_t<bf16_t, bf16_t>(a, dt, gx, s);
+}
+
+// ============================================================================ wgrad2
+template <typename T> struct FragOps;
+template <> struct FragOps<bf16_t> {
+  // lane (g = lane>>4, i = lane&15): 8 pixels = two 4-pixel blocks; lane supplies the address of pixel-row q = i>>2,
+  // channel quad p = i&3 of its group's block and receives channel i of the 4 pixels (ds_read_b64_tr_b16).
+  static constexpr int kSteps = 1;       // MFMA k-steps per 32-pixel wave slice
+  __device__ static __forceinline__ Vec16 load(const char* base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
+    Vec16 v;
+    v.w[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    v.w[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    v.w[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    v.w[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return v;
+  }
+};
+
+// LDS carve: [P tile: 128 x TA][G patch: rows x PW x TB][sToff: 32 ints][sProP 1024 f][sProG 1024 f]; the accumulator
+// staging buffer of the flush aliases the front of the region.
+template <typename T, int TA16, int TB16>
+__global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int ES = sizeof(T);
+  constexpr int TA = TA16 * 16, TB = TB16 * 16;
+  constexpr int MAXTG = (48 / (TA16 * TB16)) > 16 ? 16 : (48 / (TA16 * TB16));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TileGeom g = a.g;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, r = lane & 15;
+  const int nb_tiles = (a.Cb + TB - 1) / TB;
+  const int a0 = (blockIdx.y / nb_tiles) * TA, b0 = (blockIdx.y % nb_tiles) * TB;
+  const int tap0 = blockIdx.z * a.TG;
+  const int tg_n = min(a.TG, a.ntaps - tap0);
+  char* sP = smem;                                                     // [128][TA]
+  char* sG = sP + 128 * TA * ES;                                       // patch
+  const int patch_bytes = g.segs * g.PR * g.PW * TB * ES;
+  int* sToff = reinterpret_cast<int*>(sG + patch_bytes);
+  float* sProP = reinterpret_cast<float*>(sToff + 32);
+  float* sProG = sProP + 1024;
+  const T* __restrict__ Pp = reinterpret_cast<const T*>(a.P);
+  const T* __restrict__ Gp = reinterpret_cast<const T*>(a.G);
+  const bool proP = a.proP_scale != nullptr, proG = a.proG_scale != nullptr;
+  if (t < tg_n) {
+    const int tap = tap0 + t, kh = tap / a.ksz, kw = tap - kh * a.ksz;
+    sToff[t] = (kh * g.PW + kw) * TB * ES;          // patch origin is (q*SI - pad): tap (kh,kw) sits at +kh rows, +kw cols
+  }
+  if (proP) for (int i = t; i < TA; i += 256) {
+    const bool ok = a0 + i < a.Ca;
+    sProP[i] = ok ? a.proP_scale[a0 + i] : 0.f; sProP[512 + i] = ok ? a.proP_shift[a0 + i] : 0.f;
+  }
+  if (proG) for (int i = t; i < TB; i += 256) {
+    const bool ok = b0 + i < a.Cb;
+    sProG[i] = ok ? a.proG_scale[b0 + i] : 0.f; sProG[512 + i] = ok ? a.proG_shift[b0 + i] : 0.f;
+  }
+  f32x4 acc[MAXTG][TA16][TB16];
+#pragma unroll
+  for (int tl = 0; tl < MAXTG; ++tl)
+#pragma unroll
+    for (int ta = 0; ta < TA16; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < TB16; ++tb) acc[tl][ta][tb] = (f32x4){0, 0, 0, 0};
+  const int npix_tile = g.segs * g.qr * g.Wq;
+  const int pv = TA / VE;
+
+  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
+    __syncthreads();
+    // ---- P tile: pixels of the tile are contiguous in memory
+    {
+      int n, hq0;
+      tile_origin(g, tile, 0, n, hq0);
+      const long m0 = ((long)n * g.Hq + hq0) * g.Wq;
+      long mend = g.tiles_per_img > 0 ? ((long)n * g.Hq + min(g.Hq, hq0 + g.qr)) * g.Wq : (long)min(g.N, n + g.segs) * g.Hq * g.Wq;
+      const int nvalid = (int)(mend - m0);
+      for (int v = t; v < 128 * pv; v += 256) {
+        const int pix = v / pv, cv = v - pix * pv;
+        Vec16 q = Vec16{{0, 0, 0, 0}};
+        if (pix < nvalid && a0 + cv * VE < a.Ca) {
+          q = *reinterpret_cast<const Vec16*>(Pp + (m0 + pix) * a.Ca + a0 + cv * VE);
+          if (proP) {
+            float f[VE];
+            Elem<T>::unpack(q, f);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+              const float x = f[j] * sProP[cv * VE + j] + sProP[512 + cv * VE + j];
+              f[j] = a.proP_relu ? fmaxf(x, 0.f) : x;
+            }
+            q = Elem<T>::pack(f);
+          }
+        }
+        reinterpret_cast<Vec16*>(sP)[v] = q;
+      }
+    }
+    stage_patch<T>(g, tile, Gp, a.Cb, b0, TB, proG ? sProG : nullptr, a.proG_relu, reinterpret_cast<Vec16*>(sG));
+    __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+      // ---- bf16: one MFMA k-step (32 pixels) per wave per tile; pixel of (block b, group gq, row q): 32wv + 16b + 4gq + q
+      const int q = r >> 2, pq = r & 3;
+      int offP[2], offG[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        int p = 32 * wv + 16 * b + 4 * gq + q;
+        offP[b] = p * TA * ES + pq * 8;
+        if (p >= npix_tile) p = 0;                  // P rows beyond the tile are zero; any finite G value will do
+        offG[b] = patch_index(g, p) * TB * ES + pq * 8;
+      }
+      Vec16 af[TA16];
+#pragma unroll
+      for (int ta = 0; ta < TA16; ++ta) af[ta] = FragOps<bf16_t>::load(sP, offP[0] + ta * 32, offP[1] + ta * 32);
+#pragma unroll
+      for (int tl = 0; tl < MAXTG; ++tl) {
+        if (tl < tg_n) {
+          const int toff = sToff[tl];
+#pragma unroll
+          for (int tb = 0; tb < TB16; ++tb) {
+            const Vec16 bf = FragOps<bf16_t>::load(sG, offG[0] + toff + tb * 32, offG[1] + toff + tb * 32);
+#pragma unroll
+            for (int ta = 0; ta < TA16; ++ta) acc[tl][ta][tb] = mma_bf16(af[ta], bf, acc[tl][ta][tb]);
+          }
+        }
+      }
+    } else {
+      // ---- f32: 8 MFMA 16x16x4 steps per wave per tile; pixel of (step j, group gq): 32wv + 4j + gq
+#pragma unroll 2
+      for (int j = 0; j < 8; ++j) {
+        int p = 32 * wv + 4 * j + gq;
+        const int offP = p * TA * ES + r * 4;
+        if (p >= npix_tile) p = 0;
+        const int offG = patch_index(g, p) * TB * ES + r * 4;
+        float av[TA16];
+#pragma unroll
+        for (int ta = 0; ta < TA16; ++ta) av[ta] = *reinterpret_cast<const float*>(sP + offP + ta * 64);
+#pragma unroll
+        for (int tl = 0; tl < MAXTG; ++tl) {
+          if (tl < tg_n) {
+            const int toff = sToff[tl];
+#pragma unroll
+            for (int tb = 0; tb < TB16; ++tb) {
+              const float bv = *reinterpret_cast<const float*>(sG + offG + toff + tb * 64);
+#pragma unroll
+              for (int ta = 0; ta < TA16; ++ta)
+                acc[tl][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ta], bv, acc[tl][ta][tb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- flush: reduce the 4 waves in LDS ([a_l][b_l][tl], tl fastest), then coalesced global atomics
+  __syncthreads();
+  float* sAcc = reinterpret_cast<float*>(smem);
+  const int nacc = TA * TB * tg_n;
+  for (int i = t; i < nacc; i += 256) sAcc[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int tl = 0; tl < MAXTG; ++tl) {
+    if (tl < tg_n) {
+#pragma unroll
+      for (int ta = 0; ta < TA16; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB16; ++tb)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int al = 16 * ta + 4 * gq + jj, bl = 16 * tb + r;
+            atomicAdd(&sAcc[(al * TB + bl) * tg_n + tl], acc[tl][ta][tb][jj]);
+          }
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < nacc; i += 256) {
+    const int tl = i % tg_n, ab = i / tg_n;
+    const int bl = ab % TB, al = ab / TB;
+    if (a0 + al < a.Ca && b0 + bl < a.Cb_valid)
+      atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tl], sAcc[i] * a.scale);
+  }
+}
+
+size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB) {
+  const size_t es = dtype_size(dt);
+  const size_t stage = (size_t)128 * TA * es + (size_t)a.g.segs * a.g.PR * a.g.PW * TB * es + 32 * 4 + 2048 * 4;
+  const size_t accb = (size_t)TA * TB * a.TG * 4;
+  return stage > accb ? stage : accb;
+}
+
+template <typename T>
+static int launch_wgrad2_t(const Wgrad2Args& a, int dt, dim3 grid, int ta16, int tb16, hipStream_t s) {
+  const size_t lds = wgrad2_lds_bytes(a, dt, ta16 * 16, tb16 * 16);
+  dim3 block(256);
+#define MMVAE_W2(A_, B_) hipLaunchKernelGGL((wgrad2_kernel<T, A_, B_>), grid, block, lds, s, a)
+  if (ta16 == 1 && tb16 == 1) MMVAE_W2(1, 1);
+  else if (ta16 == 1 && tb16 == 2) MMVAE_W2(1, 2);
+  else if (ta16 == 2 && tb16 == 1) MMVAE_W2(2, 1);
+  else if (ta16 == 2 && tb16 == 2) MMVAE_W2(2, 2);
+  else if (ta16 == 4 && tb16 == 2) MMVAE_W2(4, 2);
+  else if (ta16 == 2 && tb16 == 4) MMVAE_W2(2, 4);
+  else if (ta16 == 4 && tb16 == 4) MMVAE_W2(4, 4);
+  else if (ta16 == 4 && tb16 == 1) MMVAE_W2(4, 1);
+  else if (ta16 == 1 && tb16 == 4) MMVAE_W2(1, 4);
+  else { set_error("wgrad2: tile %dx%d unsupported", ta16, tb16); return MMVAE_ERR_UNSUPPORTED; }
+#undef MMVAE_W2
+  return check_launch("wgrad2");
+}
+
+int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s) {
+  dim3 grid(gx, tiles_ab, zg);
+  return dt == DT_F32 ? launch_wgrad2_t<float>(a, dt, grid, ta16, tb16, s) : launch_wgrad2_t<bf16_t>(a, dt, grid, ta16, tb16, s);
+}
+
+}  // namespace mmvae

@@ -48,6 +48,33 @@ struct WgradArgs {
 };
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
 
+// ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
+// A tile is up to 128 q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.
+// Its input patch per segment is PR x PW pixels starting at input (hq0*SI + oh, ow).
+struct TileGeom { int N, Hq, Wq, Hi, Wi, SI, oh, ow, segs, qr, PR, PW, tiles_per_img, ntiles; };
+bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w);
+struct Phase2 { TileGeom g; int ph, pw, ntaps, tap0; long w_off; };
+struct Gather2Args {
+  const void* x; const void* w; void* y;
+  const float* pro_scale; const float* pro_shift; int pro_relu;
+  const float* bias; float* stats; int accumulate;
+  int Cin, Cout, Ho, Wo, SO;
+  int nphase; Phase2 phases[kMaxPhases]; Tap taps[kMaxTaps];
+};
+size_t gather2_lds_bytes(const Gather2Args& a, int dt, int CT);
+int launch_gather2(int dt, int out_dt, const Gather2Args& a, int gx, hipStream_t s);
+struct Wgrad2Args {
+  const void* P; const void* G; float* dW;
+  const float* proP_scale; const float* proP_shift; int proP_relu;
+  const float* proG_scale; const float* proG_shift; int proG_relu;
+  TileGeom g;
+  int Ca, Cb, Cb_valid, ksz, ntaps, TG;
+  int sA, sB; int tap_off[25]; float scale;
+};
+size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB);
+int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s);
+bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
+
 // ---------------------------------------------------------------- weight packing
 // dst[(col*ntaps + t)*K + k] = T(scale * src[col*s_col + k*s_k + tap_off[t]])
 struct PackArgs {

@@ -1,0 +1,62 @@
+"""Developer diagnostic (not a test): per-parameter gradient / output error table of the HIP VAE vs the CPU oracle."""
+import importlib
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import vae_oracle as O  # noqa: E402
+
+
+def main(dt="f32", z=32, S=64, oc=1, N=8, mmd=0.0):
+    M = importlib.import_module("moving-mnist-vae_amd.model")
+    dev = torch.device("cuda")
+    spec = O.state_spec(1, z, oc, S, True)
+    state = O.filled_state(spec, seed=0)
+    labels = O.synthetic_labels(N, S, seed=11)
+    image = O.normalise(labels, S)
+    cat = oc > 1
+    target = labels if cat else image
+    torch.manual_seed(5)
+    eps, ts = torch.randn(N, z, 1, 1), torch.randn(N, z)
+    w = torch.ones(oc) if cat else None
+    osd = {k: v.clone() for k, v in state.items()}
+    pn = [k for k, _, kind in spec if kind in ("conv", "convT", "bias", "bn_w", "bn_b")]
+    for k in pn:
+        osd[k].requires_grad_(True)
+    mu, lv, enc, rec = O.vae_forward(osd, image, eps, S, True, True)
+    loss, px, kl, mm = O.vae_loss(target, mu, lv, enc, rec, ts, nll=1, kl=1, mmd=mmd, sigma_decoder=0.1, categorical=cat, class_weight=w)
+    loss.backward()
+    m = M.VAE(1, 32, oc, 2, z, False, False, 4, "ReLu", 1, 1, mmd, True, 0.1, S, compute_dtype=dt)
+    m.load_state_dict(state)
+    m.to(dev).train()
+    m.injected_eps, m.injected_true_samples = eps.to(dev), ts.to(dev)
+    args = types.SimpleNamespace(data_ratio_of_labels=w.to(dev) if cat else None)
+    hmu, hlv, henc, hrec = m(image.to(dev))
+    hloss, hnll, hkl, hmmd = m.loss(target.to(dev), hmu, hlv, henc, hrec, dev, args)
+    hloss.backward()
+    torch.cuda.synchronize()
+
+    def re(a, b):
+        return ((a.detach().cpu().float() - b.detach()).norm() / (b.detach().norm() + 1e-20)).item()
+
+    print(f"== {dt} z={z} S={S} oc={oc} N={N} mmd={mmd}")
+    print(f"loss {hloss.item():.6f} vs {loss.item():.6f} | nll {hnll:.6f} vs {px.item()/N:.6f} | kl {hkl:.6f} vs {kl.item()/N:.6f} | mmd {hmmd:.6f} vs {mm.item()/N:.6f}")
+    print(f"mu {re(hmu, mu):.2e} logvar {re(hlv, lv):.2e} enc {re(henc, enc):.2e} recon {re(hrec, rec):.2e}")
+    hp = dict(m.named_parameters())
+    for k in reversed(pn):
+        e = re(hp[k].grad, osd[k].grad)
+        print(f"  grad {k:45s} rel {e:.2e} |ref| {osd[k].grad.norm().item():.3e}" + ("   <<<<" if e > (2e-3 if dt == 'f32' else 0.1) else ""))
+    sd = m.state_dict()
+    worst = max(((sd[k].cpu() - osd[k]).abs().max().item(), k) for k, _, kind in spec if kind in ("bn_rm", "bn_rv"))
+    print("worst running-stat abs err", worst)
+
+
+if __name__ == "__main__":
+    main("f32")
+    main("bf16")
+    main("f32", oc=2, N=4)
+    main("f32", z=128, S=28, N=5, mmd=3.0)

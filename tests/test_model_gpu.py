@@ -1,0 +1,254 @@
+"""GPU: the HIP VAE against (a) the reference-generated goldens and (b) the CPU oracle run in the same process.
+
+Tolerances (written here as the contract):
+  f32 mode  (exact-f32 MFMA, f32 activations): loss/nll rel 2e-5, kl/mmd rel 1e-4, mu/logvar abs 2e-4,
+            recon abs 2e-3 (post-BatchNorm values are O(1)), gradient table rel 2e-3 of each tensor's norm.
+  bf16 mode (bf16 activations + bf16 MFMA, f32 accumulate/statistics): loss/nll rel 1e-3 (BASELINE.json:
+            "ELBO within 1e-3 of CPU reference", relative), kl rel 5e-2, mu/logvar abs 0.15.  Gradients of this
+            BatchNorm-heavy net are inherently noisy in bf16 (torch's own CPU bf16 autocast of the oracle is 3%..40%
+            off per tensor at the filler weights), so the golden table is only a sanity bound there (norms within
+            50%) and the real gate is test_bf16_gradient_noise_not_worse_than_torch_autocast: per tensor,
+            |g_hip - g_fp32| <= 1.5 * |g_autocast - g_fp32| + 2% of |g_fp32|, evaluated live against the oracle.
+"""
+import importlib
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from golden_util import CASE_NAMES, TRAJ_NAMES, LabelLoader, load, make_args  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+TOL = {
+    "f32": dict(loss=2e-5, kl=1e-4, mmd=2e-4, lat=2e-4, recon=2e-3, gnorm=2e-3, gval=3e-3, bn=1e-4),
+    "bf16": dict(loss=1e-3, kl=5e-2, mmd=5e-2, lat=0.15, recon=0.25, gnorm=0.5, gval=1.0, bn=2e-2),
+}
+
+
+def _M():
+    return importlib.import_module("moving-mnist-vae_amd.model")
+
+
+def build_model(cfg, dt, O):
+    M = _M()
+    m = M.VAE(1, 32, cfg["out_ch"], 2, cfg["z"], False, False, 4, "ReLu", 1, cfg["kl"], cfg["mmd"], cfg["rsample"], cfg["sigma"],
+              cfg["S"], compute_dtype=dt)
+    spec = O.state_spec(1, cfg["z"], cfg["out_ch"], cfg["S"], cfg["rsample"])
+    m.load_state_dict(O.filled_state(spec, seed=0))
+    return m.to("cuda").train(), spec
+
+
+def run_case(name, dt, O, verbose=False):
+    g, cfg = load(name)
+    t = TOL[dt]
+    n, z, S = cfg["N"], cfg["z"], cfg["S"]
+    dev = torch.device("cuda")
+    m, spec = build_model(cfg, dt, O)
+    labels = O.synthetic_labels(n, S, seed=int(g["labels_seed"]))
+    image = O.normalise(labels, S)
+    categorical = cfg["out_ch"] > 1
+    target = (labels if categorical else image).to(dev)
+    if cfg["rsample"]:
+        m.injected_eps = torch.from_numpy(g["eps"]).view(n, z, 1, 1).to(dev)
+    m.injected_true_samples = torch.from_numpy(g["true_samples"]).to(dev)
+    args = make_args(cfg, dev)
+    mu, lv, enc, rec = m(image.to(dev))
+    loss, nll, kl, mmd = m.loss(target, mu, lv, enc, rec, dev, args)
+    m.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    rep = OrderedDict()
+
+    def rel(a, b):
+        return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+    rep["loss"] = (rel(loss.item(), g["loss"]), t["loss"])
+    rep["nll"] = (rel(nll, g["nll"]), t["loss"])
+    rep["kl"] = (abs(kl - float(g["kl"])) / max(abs(float(g["kl"])), 1.0), t["kl"])
+    rep["mmd"] = (abs(mmd - float(g["mmd"])) / max(abs(float(g["mmd"])), 1.0), t["mmd"])
+    rep["mu"] = (float(np.abs(mu.detach().view(n, -1)[:8].cpu().numpy() - g["mu"]).max()), t["lat"])
+    if cfg["rsample"]:
+        rep["logvar"] = (float(np.abs(lv.detach().view(n, -1)[:8].cpu().numpy() - g["logvar"]).max()), t["lat"])
+    rc = rec.detach().cpu()
+    assert tuple(rc.shape) == (n, cfg["out_ch"], S, S)
+    rep["recon_sub"] = (float(np.abs(rc[:, :, ::8, ::8].numpy() - g["recon_sub"]).max()), t["recon"])
+    rep["recon_sumsq"] = (rel((rc.double() ** 2).sum().item(), g["recon_sumsq"]), 10 * t["loss"] if dt == "f32" else 2e-2)
+    names = [str(s) for s in g["grad_names"]]
+    worst_n, worst_v, wn_name = 0.0, 0.0, ""
+    params = dict(m.named_parameters())
+    for i, k in enumerate(names):
+        gr = params[k].grad
+        assert gr is not None, k
+        gn = float(g["grad_norm"][i])
+        gmax = float(g["grad_norm"].max())
+        if gn < 1e-5 * gmax:
+            # analytically-zero gradient (decoder.conv2.bias sits in front of a BatchNorm): the reference value is
+            # rounding noise; only require ours to be noise-sized too
+            assert gr.double().norm().item() < 1e-3 * gmax, k
+            continue
+        e = abs(gr.double().norm().item() - gn) / max(gn, 1e-6 * gmax)
+        if e > worst_n:
+            worst_n, wn_name = e, k
+        flat = gr.flatten().cpu()
+        for j, idx in enumerate(g["grad_idx"][i]):
+            if idx >= 0:
+                ev = abs(flat[idx].item() - float(g["grad_val"][i][j])) / max(gn, 1e-6 * float(g["grad_norm"].max()))
+                worst_v = max(worst_v, ev)
+    rep["grad_norm[" + wn_name + "]"] = (worst_n, t["gnorm"])
+    rep["grad_val"] = (worst_v, t["gval"])
+    sd = m.state_dict()
+    wb = 0.0
+    for i, k in enumerate([str(s) for s in g["bn_names"]]):
+        wb = max(wb, rel(sd[k].double().norm().item(), g["bn_norm"][i]))
+    rep["bn_running"] = (wb, t["bn"])
+    assert int(sd["encoder.bn1.num_batches_tracked"]) == 1
+    # eval-mode reconstruction (model.py:353-362) from the freshly updated running statistics
+    m.eval()
+    with torch.no_grad():
+        ev = m.get_reconstruction(torch.from_numpy(g["eval_z"]).view(4, z, 1, 1).to(dev)).cpu()
+    rep["eval_recon"] = (float(np.abs(ev[:, :, ::8, ::8].numpy() - g["eval_recon_sub"]).max()), t["recon"])
+    if verbose:
+        print(f"[{dt}] {name}: " + "  ".join(f"{k}={v[0]:.2e}{'' if v[0] <= v[1] else '(!>' + format(v[1], '.0e') + ')'}" for k, v in rep.items()),
+              flush=True)
+    return rep
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_hip_model_matches_reference_golden(name, dt, oracle):
+    rep = run_case(name, dt, oracle)
+    bad = {k: v for k, v in rep.items() if not (v[0] == v[0] and v[0] <= v[1])}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("name", TRAJ_NAMES)
+def test_train_loop_trajectory_matches_reference(name, dt, oracle, pkg):
+    """pkg.train + HIP VAE + FusedAdam vs the 3-step trajectory of train + reference model + torch.optim.Adam."""
+    O = oracle
+    g, cfg = load(name)
+    M = _M()
+    dev = torch.device("cuda")
+    m, spec = build_model(cfg, dt, O)
+    opt = M.FusedAdam(list(m.parameters()))
+    eps, ts = g["eps"], g["true_samples"]
+    step = {"i": 0}
+
+    class Inject:   # per-step noise injection in the order the reference consumed its CPU generator
+        def __iter__(self_inner):
+            for b in LabelLoader(O, cfg["N"], cfg["S"], cfg["steps"], int(g["loader_seed0"])):
+                i = step["i"]
+                m.injected_eps = torch.from_numpy(eps[i]).view(cfg["N"], cfg["z"], 1, 1).to(dev)
+                m.injected_true_samples = torch.from_numpy(ts[i]).to(dev)
+                step["i"] += 1
+                yield b
+
+    out = pkg.train(m, Inject(), opt, dev, make_args(cfg, dev), epoch=0, data_mean=O.DATA_MEAN, data_std=O.DATA_STD)
+    torch.cuda.synchronize()
+    tl = 3e-4 if dt == "f32" else 5e-3     # step 2-3 include the Adam update (sign-like, amplifies tiny gradient differences)
+    np.testing.assert_allclose(out[0], g["loss"], rtol=tl)
+    np.testing.assert_allclose(out[1], g["nll"], rtol=tl)
+    np.testing.assert_allclose(out[2], g["kl"], rtol=20 * tl, atol=1e-3)
+    sd = m.state_dict()
+    for i, k in enumerate([str(s) for s in g["param_names"]]):
+        pn = float(g["param_norm"][i])
+        assert abs(sd[k].double().norm().item() - pn) <= (2e-3 if dt == "f32" else 2e-2) * max(pn, 1e-3), k
+    assert int(sd["decoder.bn2.num_batches_tracked"]) == cfg["steps"]
+    # gradients landed in the flat buffer without copies, optimiser state has the torch.optim.Adam layout
+    p0 = next(m.parameters())
+    assert p0.grad is not None and p0.grad.data_ptr() == m._G[0].data_ptr()
+    st = opt.state_dict()["state"]
+    assert len(st) == len(list(m.parameters())) and set(st[0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("name", ["c1_gauss", "c1_cat_w1", "gauss_z128"])
+def test_bf16_gradient_noise_not_worse_than_torch_autocast(name, oracle):
+    O = oracle
+    g, cfg = load(name)
+    n, z, S = cfg["N"], cfg["z"], cfg["S"]
+    dev = torch.device("cuda")
+    spec = O.state_spec(1, z, cfg["out_ch"], S, True)
+    pn = [k for k, _, kind in spec if kind in ("conv", "convT", "bias", "bn_w", "bn_b")]
+    labels = O.synthetic_labels(n, S, seed=int(g["labels_seed"]))
+    image = O.normalise(labels, S)
+    categorical = cfg["out_ch"] > 1
+    target = labels if categorical else image
+    eps = torch.from_numpy(g["eps"]).view(n, z, 1, 1)
+    ts = torch.from_numpy(g["true_samples"])
+    args = make_args(cfg)
+
+    def oracle_grads(autocast):
+        sd = O.filled_state(spec, seed=0)
+        for k in pn:
+            sd[k].requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            mu, lv, enc, rec = O.vae_forward(sd, image, eps, S, True, True)
+        loss = O.vae_loss(target, mu.float(), lv.float(), enc.float(), rec.float(), ts, nll=1, kl=cfg["kl"], mmd=cfg["mmd"],
+                          sigma_decoder=cfg["sigma"], categorical=categorical, class_weight=args.data_ratio_of_labels)[0]
+        loss.backward()
+        return {k: sd[k].grad.detach().clone() for k in pn}
+
+    g32, g16 = oracle_grads(False), oracle_grads(True)
+    m, _ = build_model(cfg, "bf16", O)
+    m.injected_eps, m.injected_true_samples = eps.to(dev), ts.to(dev)
+    mu, lv, enc, rec = m(image.to(dev))
+    loss = m.loss(target.to(dev), mu, lv, enc, rec, dev, make_args(cfg, dev))[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    bad = {}
+    for k, p in m.named_parameters():
+        ref = g32[k]
+        if ref.norm().item() < 1e-3 * max(v.norm().item() for v in g32.values()) * 1e-3:
+            continue                                  # analytically-zero gradients (conv bias in front of a BatchNorm)
+        e_hip = (p.grad.cpu() - ref).norm().item()
+        e_auto = (g16[k] - ref).norm().item()
+        if e_hip > 1.5 * e_auto + 0.02 * ref.norm().item():
+            bad[k] = (e_hip / ref.norm().item(), e_auto / ref.norm().item())
+    assert not bad, bad
+
+
+def test_full_size_properties_bf16(oracle):
+    """BASELINE config-2 shape class (many frames, z=128, bf16) through size-independent properties: finite outputs,
+    per-channel BatchNorm statistics of the reconstruction (zero mean / unit variance by construction, model.py:193),
+    loss decomposition loss == nll + kl (mmd coefficient 0), and decreasing loss over a few Adam steps."""
+    import types
+    M = _M()
+    pkg = importlib.import_module("moving-mnist-vae_amd")
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    m = M.VAE(1, 32, 1, 2, 128, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype="bf16").to(dev).train()
+    opt = M.FusedAdam(list(m.parameters()))
+    N = 20 * 64
+    labels = oracle.synthetic_labels(N, 64, seed=2).view(64, 20, 64, 64)
+    args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
+    losses, nlls, kls, mmds = pkg.train(m, [labels] * 6, opt, dev, args, data_mean=oracle.DATA_MEAN, data_std=oracle.DATA_STD)
+    assert all(np.isfinite(losses)), losses
+    for a, b, c in zip(losses, nlls, kls):
+        assert abs(a - (b + c)) <= 1e-4 * abs(a)
+    assert losses[-1] < losses[0]
+    image = oracle.normalise(labels.view(-1, 64, 64), 64).to(dev)
+    mu, lv, enc, rec = m(image)
+    assert rec.shape == (N, 1, 64, 64)
+    assert abs(rec.mean().item()) < 1e-3 and abs(rec.var(unbiased=False).item() - 1.0) < 1e-2
+
+
+if __name__ == "__main__":
+    from oracle import vae_oracle as O
+    only = sys.argv[1:] or CASE_NAMES
+    for dt in ("f32", "bf16"):
+        for name in only:
+            try:
+                run_case(name, dt, O, verbose=True)
+            except Exception as ex:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                print(f"[{dt}] {name}: EXCEPTION {ex!r}"[:400], flush=True)
