@@ -254,20 +254,20 @@ bool conv_force_v1() {
   return v != 0;
 }
 
-bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w) {
-  if (Hq <= 0 || Wq <= 0 || Wq > 128 || N <= 0) return false;
-  g.N = N; g.Hq = Hq; g.Wq = Wq; g.Hi = Hi; g.Wi = Wi; g.SI = SI; g.oh = oh; g.ow = ow;
-  if (Hq * Wq >= 128) {
-    g.segs = 1; g.qr = 128 / Wq; if (g.qr > Hq) g.qr = Hq;
+bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w, int TP) {
+  if (Hq <= 0 || Wq <= 0 || Wq > TP || N <= 0) return false;
+  g.N = N; g.Hq = Hq; g.Wq = Wq; g.Hi = Hi; g.Wi = Wi; g.SI = SI; g.oh = oh; g.ow = ow; g.TP = TP;
+  if (Hq * Wq >= TP) {
+    g.segs = 1; g.qr = TP / Wq; if (g.qr > Hq) g.qr = Hq;
     g.tiles_per_img = (Hq + g.qr - 1) / g.qr;
     g.ntiles = N * g.tiles_per_img;
   } else {
-    g.segs = 128 / (Hq * Wq); g.qr = Hq; g.tiles_per_img = 0;
+    g.segs = TP / (Hq * Wq); g.qr = Hq; g.tiles_per_img = 0;
     g.ntiles = (N + g.segs - 1) / g.segs;
   }
   g.PR = (g.qr - 1) * SI + span_h;
   g.PW = (Wq - 1) * SI + span_w;
-  return true;
+  return g.PR < 256 && g.PW < 256 && g.segs <= 128;
 }
 
 constexpr size_t kV2MaxLds = 60 * 1024;
@@ -500,16 +500,26 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   b.P = a.P; b.G = a.G; b.dW = a.dW;
   b.proP_scale = a.proP_scale; b.proP_shift = a.proP_shift; b.proP_relu = a.proP_relu;
   b.proG_scale = a.proG_scale; b.proG_shift = a.proG_shift; b.proG_relu = a.proG_relu;
-  if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz)) return 0;
+  b.TG = wgrad2_taps_per_block(ta16, tb16, a.ntaps);
+  bool fits = false;
+  for (int TP = 128; TP >= 32 && !fits; TP >>= 1) {     // shrink the pixel tile until patch + P tile fit in LDS
+    if (TP < 128 && a.ntaps < 4) break;                 // the k-split mode (1x1 convs) needs all four k-steps
+    if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, TP)) continue;
+    fits = wgrad2_lds_bytes(b, dt, TA, TB) <= kV2MaxLds;
+  }
+  if (!fits) return 0;
   b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
-  int maxtg = 48 / (ta16 * tb16); if (maxtg > 16) maxtg = 16;
-  b.TG = a.ntaps < maxtg ? a.ntaps : maxtg;
   b.sA = a.sA; b.sB = a.sB; b.scale = a.scale;
   for (int t = 0; t < 25; ++t) b.tap_off[t] = a.tap_off[t];
-  if (wgrad2_lds_bytes(b, dt, TA, TB) > kV2MaxLds) return 0;
   const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
   const int zg = (a.ntaps + b.TG - 1) / b.TG;
   int gx = 1024 / (tiles_ab * zg); if (gx < 1) gx = 1;
+  {                                                     // each persistent block flushes its whole dW tile once:
+    const long wsize = (long)a.Ca * a.Cb * a.ntaps;     // keep the global float atomics of a launch below ~3M
+    long cap = (3L << 20) / (wsize > 0 ? wsize : 1);
+    if (cap < 2) cap = 2;
+    if (gx > cap) gx = (int)cap;
+  }
   if (gx > b.g.ntiles) gx = b.g.ntiles;
   const int rc = launch_wgrad2(dt, b, gx, tiles_ab, zg, ta16, tb16, s);
   return rc < 0 ? rc : 1;

@@ -50,35 +50,55 @@ __device__ __forceinline__ int patch_index(const TileGeom& g, int p) {
 }
 
 // Stage the patch of `Cs` channels [c0, c0+Cs) of X (tensor channels C) into LDS: layout [segs*PR][PW][Cs].
-template <typename T>
+// Loads are issued in register batches of NB (all NB in flight, then NB LDS stores): staging is latency-bound.
+template <typename T, int NB>
 __device__ __forceinline__ void stage_patch(const TileGeom& g, int tile, const T* __restrict__ X, int C, int c0, int Cs,
                                             const float* sPro, int relu, Vec16* sPatch) {
   constexpr int VE = Elem<T>::kVec;
   const int cvec = Cs / VE;
   const int rowvecs = g.PW * cvec;
   const int total = g.segs * g.PR * rowvecs;
-  for (int v = threadIdx.x; v < total; v += blockDim.x) {
-    const int row = v / rowvecs, rv = v - row * rowvecs;
-    const int pc = rv / cvec, cv = rv - pc * cvec;
-    const int seg = row / g.PR, pr = row - seg * g.PR;
-    int n, hq0;
-    tile_origin(g, tile, seg, n, hq0);
-    const int hi = hq0 * g.SI + g.oh + pr, wi = g.ow + pc;
-    Vec16 q = Vec16{{0, 0, 0, 0}};
-    if (n < g.N && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) {
-      q = *reinterpret_cast<const Vec16*>(X + ((long)(n * g.Hi + hi) * g.Wi + wi) * C + c0 + cv * VE);
-      if (sPro) {
-        float f[VE];
-        Elem<T>::unpack(q, f);
+  int n1, hq01;
+  tile_origin(g, tile, 0, n1, hq01);
+  const bool multi = g.tiles_per_img == 0;
+  const int h_base = hq01 * g.SI + g.oh;
+  for (int base = threadIdx.x; base < total; base += 256 * NB) {
+    Vec16 q[NB];
+    int cvs[NB];
 #pragma unroll
-        for (int j = 0; j < VE; ++j) {
-          const float x = f[j] * sPro[cv * VE + j] + sPro[512 + cv * VE + j];
-          f[j] = relu ? fmaxf(x, 0.f) : x;
+    for (int k = 0; k < NB; ++k) {
+      const int v = base + 256 * k;
+      q[k] = Vec16{{0, 0, 0, 0}};
+      cvs[k] = -1;
+      if (v < total) {
+        const int row = v / rowvecs, rv = v - row * rowvecs;
+        const int pc = rv / cvec, cv = rv - pc * cvec;
+        const int seg = row / g.PR, pr = row - seg * g.PR;
+        const int n = multi ? n1 + seg : n1;
+        const int hi = h_base + pr, wi = g.ow + pc;
+        if (n < g.N && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) {
+          q[k] = *reinterpret_cast<const Vec16*>(X + ((long)(n * g.Hi + hi) * g.Wi + wi) * C + c0 + cv * VE);
+          cvs[k] = cv;
         }
-        q = Elem<T>::pack(f);
       }
     }
-    sPatch[v] = q;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int v = base + 256 * k;
+      if (v < total) {
+        if (sPro && cvs[k] >= 0) {               // padding stays exactly zero
+          float f[VE];
+          Elem<T>::unpack(q[k], f);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) {
+            const float x = f[j] * sPro[cvs[k] * VE + j] + sPro[512 + cvs[k] * VE + j];
+            f[j] = relu ? fmaxf(x, 0.f) : x;
+          }
+          q[k] = Elem<T>::pack(f);
+        }
+        sPatch[v] = q[k];
+      }
+    }
   }
 }
 
@@ -149,18 +169,25 @@ __global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
   const int npix_tile = g.segs * g.qr * g.Wq;
   const int nks = kvp >> 2;
   const char* patch_bytes = reinterpret_cast<const char*>(sPatch);
+  // tile-independent decode of this lane's two pixels
+  int pbase[2], pseg[2], pj[2], pwq[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; ++pt) {
+    const int p = 32 * wv + 16 * pt + r;
+    const int pc = p < npix_tile ? p : 0;
+    pbase[pt] = patch_index(g, pc) * a.Cin * ES;
+    const int per_seg = g.qr * g.Wq;
+    pseg[pt] = pc / per_seg;
+    const int rem = pc - pseg[pt] * per_seg;
+    pj[pt] = rem / g.Wq;
+    pwq[pt] = rem - pj[pt] * g.Wq;
+    if (p >= npix_tile) pseg[pt] = -1;
+  }
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
     __syncthreads();                 // previous tile's fragment reads are done (also orders the block prologue)
-    stage_patch<T>(g, tile, X, a.Cin, 0, a.Cin, has_pro ? sPro : nullptr, a.pro_relu, sPatch);
+    stage_patch<T, 4>(g, tile, X, a.Cin, 0, a.Cin, has_pro ? sPro : nullptr, a.pro_relu, sPatch);
     __syncthreads();
-    int pbase[2];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      int p = 32 * wv + 16 * pt + r;
-      if (p >= npix_tile) p = 0;
-      pbase[pt] = patch_index(g, p) * a.Cin * ES;
-    }
     f32x4 acc[CT16][2];
 #pragma unroll
     for (int c = 0; c < CT16; ++c) { acc[c][0] = (f32x4){0, 0, 0, 0}; acc[c][1] = (f32x4){0, 0, 0, 0}; }
@@ -179,14 +206,11 @@ __global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
     // ---- epilogue: lane holds couts 16c + 4gq + j of pixel 32wv + 16pt + r
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
-      const int p = 32 * wv + 16 * pt + r;
-      if (p < npix_tile) {
-        const int per_seg = g.qr * g.Wq;
-        const int seg = p / per_seg, rem = p - seg * per_seg;
-        const int j = rem / g.Wq, wq = rem - j * g.Wq;
+      if (pseg[pt] >= 0) {
+        const int wq = pwq[pt];
         int n, hq0;
-        tile_origin(g, tile, seg, n, hq0);
-        const int hq = hq0 + j;
+        tile_origin(g, tile, pseg[pt], n, hq0);
+        const int hq = hq0 + pj[pt];
         if (n < g.N && hq < g.Hq) {
           const long obase = ((long)(n * a.Ho + hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw)) * a.Cout;
 #pragma unroll
@@ -262,6 +286,7 @@ static int launch_gather2_t(const Gather2Args& a, int dt, int gx, hipStream_t s)
     case 3: case 4: hipLaunchKernelGGL((gather2_kernel<T, TO, 4>), grid, block, lds, s, a); break;
     default: set_error("gather2: Cout=%d too large", a.Cout); return MMVAE_ERR_UNSUPPORTED;
   }
+
   int rc = check_launch("gather2");
   return rc ? rc : gx * a.nphase;
 }
@@ -290,14 +315,24 @@ template <> struct FragOps<bf16_t> {
   }
 };
 
-// LDS carve: [P tile: 128 x TA][G patch: rows x PW x TB][sToff: 32 ints][sProP 1024 f][sProG 1024 f]; the accumulator
+// LDS carve: [P tile: TP x TA][G patch: rows x PW x TB][sToff: 32 ints][sProP 1024 f][sProG 1024 f]; the accumulator
 // staging buffer of the flush aliases the front of the region.
-template <typename T, int TA16, int TB16>
+// Work split over the 4 waves of a block:
+//   TS = true  (>= 4 taps): wave w owns taps w, w+4, ... of the block's tap group and runs all four 32-pixel k-steps of
+//                           the tile -> only MAXT*TA16*TB16 accumulator tiles per wave (registers -> occupancy);
+//   TS = false (1x1 convs): wave w owns k-step w of the tile and every tap.
+template <int TA16, int TB16> struct Wgrad2Cfg {
+  static constexpr int kUnits = TA16 * TB16;
+  static constexpr int kMaxT = (12 / kUnits) < 1 ? 1 : ((12 / kUnits) > 4 ? 4 : (12 / kUnits));
+};
+
+template <typename T, int TA16, int TB16, bool TS>
 __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
   constexpr int VE = Elem<T>::kVec;
   constexpr int ES = sizeof(T);
   constexpr int TA = TA16 * 16, TB = TB16 * 16;
-  constexpr int MAXTG = (48 / (TA16 * TB16)) > 16 ? 16 : (48 / (TA16 * TB16));
+  constexpr int MAXT = Wgrad2Cfg<TA16, TB16>::kMaxT;
+  constexpr int NKS = TS ? 4 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TileGeom g = a.g;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, r = lane & 15;
@@ -306,7 +341,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
   const int tap0 = blockIdx.z * a.TG;
   const int tg_n = min(a.TG, a.ntaps - tap0);
   char* sP = smem;                                                     // [128][TA]
-  char* sG = sP + 128 * TA * ES;                                       // patch
+  char* sG = sP + g.TP * TA * ES;                                      // patch
   const int patch_bytes = g.segs * g.PR * g.PW * TB * ES;
   int* sToff = reinterpret_cast<int*>(sG + patch_bytes);
   float* sProP = reinterpret_cast<float*>(sToff + 32);
@@ -326,15 +361,32 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     const bool ok = b0 + i < a.Cb;
     sProG[i] = ok ? a.proG_scale[b0 + i] : 0.f; sProG[512 + i] = ok ? a.proG_shift[b0 + i] : 0.f;
   }
-  f32x4 acc[MAXTG][TA16][TB16];
+  f32x4 acc[MAXT][TA16][TB16];
 #pragma unroll
-  for (int tl = 0; tl < MAXTG; ++tl)
+  for (int tl = 0; tl < MAXT; ++tl)
 #pragma unroll
     for (int ta = 0; ta < TA16; ++ta)
 #pragma unroll
       for (int tb = 0; tb < TB16; ++tb) acc[tl][ta][tb] = (f32x4){0, 0, 0, 0};
   const int npix_tile = g.segs * g.qr * g.Wq;
-  const int pv = TA / VE;
+  constexpr int pv = TA / VE;
+  // tile-independent LDS offsets of this lane's fragment pixels (bf16: 2 four-pixel blocks per k-step)
+  int offP[NKS][2], offG[NKS][2];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int i = 0; i < NKS; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        int p = 32 * (TS ? i : wv) + 16 * b + 4 * gq + (r >> 2);
+        offP[i][b] = p * TA * ES + (r & 3) * 8;
+        if (p >= npix_tile) p = 0;                  // P rows beyond the tile are zero; any finite G value will do
+        offG[i][b] = patch_index(g, p) * TB * ES + (r & 3) * 8;
+      }
+  }
+  // this wave's taps (local index within the block's tap group)
+  int my_tap[MAXT];
+#pragma unroll
+  for (int tl = 0; tl < MAXT; ++tl) my_tap[tl] = TS ? wv + 4 * tl : tl;
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
     __syncthreads();
@@ -343,9 +395,9 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
       int n, hq0;
       tile_origin(g, tile, 0, n, hq0);
       const long m0 = ((long)n * g.Hq + hq0) * g.Wq;
-      long mend = g.tiles_per_img > 0 ? ((long)n * g.Hq + min(g.Hq, hq0 + g.qr)) * g.Wq : (long)min(g.N, n + g.segs) * g.Hq * g.Wq;
+      const long mend = g.tiles_per_img > 0 ? ((long)n * g.Hq + min(g.Hq, hq0 + g.qr)) * g.Wq : (long)min(g.N, n + g.segs) * g.Hq * g.Wq;
       const int nvalid = (int)(mend - m0);
-      for (int v = t; v < 128 * pv; v += 256) {
+      for (int v = t; v < g.TP * pv; v += 256) {
         const int pix = v / pv, cv = v - pix * pv;
         Vec16 q = Vec16{{0, 0, 0, 0}};
         if (pix < nvalid && a0 + cv * VE < a.Ca) {
@@ -364,102 +416,140 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         reinterpret_cast<Vec16*>(sP)[v] = q;
       }
     }
-    stage_patch<T>(g, tile, Gp, a.Cb, b0, TB, proG ? sProG : nullptr, a.proG_relu, reinterpret_cast<Vec16*>(sG));
+    stage_patch<T, 8>(g, tile, Gp, a.Cb, b0, TB, proG ? sProG : nullptr, a.proG_relu, reinterpret_cast<Vec16*>(sG));
     __syncthreads();
+    const int nks_tile = g.TP >> 5;                   // 32-pixel k-steps in this tile size (TS mode: 4, 2 or 1)
     if constexpr (sizeof(T) == 2) {
-      // ---- bf16: one MFMA k-step (32 pixels) per wave per tile; pixel of (block b, group gq, row q): 32wv + 16b + 4gq + q
-      const int q = r >> 2, pq = r & 3;
-      int offP[2], offG[2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        int p = 32 * wv + 16 * b + 4 * gq + q;
-        offP[b] = p * TA * ES + pq * 8;
-        if (p >= npix_tile) p = 0;                  // P rows beyond the tile are zero; any finite G value will do
-        offG[b] = patch_index(g, p) * TB * ES + pq * 8;
-      }
-      Vec16 af[TA16];
+      for (int i = 0; i < NKS; ++i) {
+        if (TS && i >= nks_tile) break;
+        Vec16 af[TA16];
 #pragma unroll
-      for (int ta = 0; ta < TA16; ++ta) af[ta] = FragOps<bf16_t>::load(sP, offP[0] + ta * 32, offP[1] + ta * 32);
+        for (int ta = 0; ta < TA16; ++ta) af[ta] = FragOps<bf16_t>::load(sP, offP[i][0] + ta * 32, offP[i][1] + ta * 32);
 #pragma unroll
-      for (int tl = 0; tl < MAXTG; ++tl) {
-        if (tl < tg_n) {
-          const int toff = sToff[tl];
+        for (int tl = 0; tl < MAXT; ++tl) {
+          if (my_tap[tl] < tg_n) {
+            const int toff = sToff[my_tap[tl]];
 #pragma unroll
-          for (int tb = 0; tb < TB16; ++tb) {
-            const Vec16 bf = FragOps<bf16_t>::load(sG, offG[0] + toff + tb * 32, offG[1] + toff + tb * 32);
+            for (int tb = 0; tb < TB16; ++tb) {
+              const Vec16 bf = FragOps<bf16_t>::load(sG, offG[i][0] + toff + tb * 32, offG[i][1] + toff + tb * 32);
 #pragma unroll
-            for (int ta = 0; ta < TA16; ++ta) acc[tl][ta][tb] = mma_bf16(af[ta], bf, acc[tl][ta][tb]);
+              for (int ta = 0; ta < TA16; ++ta) acc[tl][ta][tb] = mma_bf16(af[ta], bf, acc[tl][ta][tb]);
+            }
           }
         }
       }
     } else {
-      // ---- f32: 8 MFMA 16x16x4 steps per wave per tile; pixel of (step j, group gq): 32wv + 4j + gq
-#pragma unroll 2
-      for (int j = 0; j < 8; ++j) {
-        int p = 32 * wv + 4 * j + gq;
-        const int offP = p * TA * ES + r * 4;
-        if (p >= npix_tile) p = 0;
-        const int offG = patch_index(g, p) * TB * ES + r * 4;
-        float av[TA16];
+      // ---- f32 (validation mode): 8 MFMA 16x16x4 steps per 32-pixel k-step; pixel of (step j, group gq): 32ks + 4j + gq
+      for (int i = 0; i < NKS; ++i) {
+        if (TS && i >= nks_tile) break;
+        const int ks = TS ? i : wv;
+        for (int j = 0; j < 8; ++j) {
+          int p = 32 * ks + 4 * j + gq;
+          const int oP = p * TA * ES + r * 4;
+          if (p >= npix_tile) p = 0;
+          const int oG = patch_index(g, p) * TB * ES + r * 4;
+          float av[TA16];
 #pragma unroll
-        for (int ta = 0; ta < TA16; ++ta) av[ta] = *reinterpret_cast<const float*>(sP + offP + ta * 64);
+          for (int ta = 0; ta < TA16; ++ta) av[ta] = *reinterpret_cast<const float*>(sP + oP + ta * 64);
 #pragma unroll
-        for (int tl = 0; tl < MAXTG; ++tl) {
-          if (tl < tg_n) {
-            const int toff = sToff[tl];
+          for (int tl = 0; tl < MAXT; ++tl) {
+            if (my_tap[tl] < tg_n) {
+              const int toff = sToff[my_tap[tl]];
 #pragma unroll
-            for (int tb = 0; tb < TB16; ++tb) {
-              const float bv = *reinterpret_cast<const float*>(sG + offG + toff + tb * 64);
+              for (int tb = 0; tb < TB16; ++tb) {
+                const float bv = *reinterpret_cast<const float*>(sG + oG + toff + tb * 64);
 #pragma unroll
-              for (int ta = 0; ta < TA16; ++ta)
-                acc[tl][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ta], bv, acc[tl][ta][tb], 0, 0, 0);
+                for (int ta = 0; ta < TA16; ++ta)
+                  acc[tl][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ta], bv, acc[tl][ta][tb], 0, 0, 0);
+              }
             }
           }
         }
       }
     }
   }
-  // ---- flush: reduce the 4 waves in LDS ([a_l][b_l][tl], tl fastest), then coalesced global atomics
+  // ---- flush.  Preferred: combine the waves in LDS as [a_l][b_l][tap] (tap fastest) and issue global atomics on
+  // consecutive addresses.  When that image does not fit the block's LDS, go tap by tap through a [a_l][b_l] buffer.
   __syncthreads();
   float* sAcc = reinterpret_cast<float*>(smem);
   const int nacc = TA * TB * tg_n;
-  for (int i = t; i < nacc; i += 256) sAcc[i] = 0.f;
-  __syncthreads();
+  if ((size_t)nacc * 4 <= (size_t)a.lds_bytes) {
+    for (int i = t; i < nacc; i += 256) sAcc[i] = 0.f;
+    __syncthreads();
 #pragma unroll
-  for (int tl = 0; tl < MAXTG; ++tl) {
-    if (tl < tg_n) {
+    for (int tl = 0; tl < MAXT; ++tl) {
+      if (my_tap[tl] < tg_n) {
 #pragma unroll
-      for (int ta = 0; ta < TA16; ++ta)
+        for (int ta = 0; ta < TA16; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < TB16; ++tb)
+          for (int tb = 0; tb < TB16; ++tb)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int al = 16 * ta + 4 * gq + jj, bl = 16 * tb + r;
-            atomicAdd(&sAcc[(al * TB + bl) * tg_n + tl], acc[tl][ta][tb][jj]);
-          }
+            for (int jj = 0; jj < 4; ++jj) {
+              const int al = 16 * ta + 4 * gq + jj, bl = 16 * tb + r;
+              atomicAdd(&sAcc[(al * TB + bl) * tg_n + my_tap[tl]], acc[tl][ta][tb][jj]);
+            }
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < nacc; i += 256) {
+      const int tl = i % tg_n, ab = i / tg_n;
+      const int bl = ab % TB, al = ab / TB;
+      if (a0 + al < a.Ca && b0 + bl < a.Cb_valid)
+        atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tl], sAcc[i] * a.scale);
+    }
+  } else {
+#pragma unroll
+    for (int tl = 0; tl < MAXT; ++tl) {
+      for (int w = 0; w < (TS ? 4 : 1); ++w) {
+        const int tap_l = TS ? w + 4 * tl : tl;          // uniform over the block
+        if (tap_l >= tg_n) continue;
+        for (int i = t; i < TA * TB; i += 256) sAcc[i] = 0.f;
+        __syncthreads();
+        if (!TS || wv == w) {
+#pragma unroll
+          for (int ta = 0; ta < TA16; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TB16; ++tb)
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj)
+                atomicAdd(&sAcc[(16 * ta + 4 * gq + jj) * TB + 16 * tb + r], acc[tl][ta][tb][jj]);
+        }
+        __syncthreads();
+        for (int i = t; i < TA * TB; i += 256) {
+          const int bl = i % TB, al = i / TB;
+          if (a0 + al < a.Ca && b0 + bl < a.Cb_valid)
+            atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tap_l], sAcc[i] * a.scale);
+        }
+        __syncthreads();
+      }
     }
   }
-  __syncthreads();
-  for (int i = t; i < nacc; i += 256) {
-    const int tl = i % tg_n, ab = i / tg_n;
-    const int bl = ab % TB, al = ab / TB;
-    if (a0 + al < a.Ca && b0 + bl < a.Cb_valid)
-      atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tl], sAcc[i] * a.scale);
-  }
+}
+
+int wgrad2_taps_per_block(int ta16, int tb16, int ntaps) {
+  int mt = 12 / (ta16 * tb16); if (mt < 1) mt = 1; if (mt > 4) mt = 4;
+  const int tg = ntaps >= 4 ? 4 * mt : mt;
+  return tg < ntaps ? tg : ntaps;
 }
 
 size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB) {
   const size_t es = dtype_size(dt);
-  const size_t stage = (size_t)128 * TA * es + (size_t)a.g.segs * a.g.PR * a.g.PW * TB * es + 32 * 4 + 2048 * 4;
-  const size_t accb = (size_t)TA * TB * a.TG * 4;
-  return stage > accb ? stage : accb;
+  const size_t stage = (size_t)a.g.TP * TA * es + (size_t)a.g.segs * a.g.PR * a.g.PW * TB * es + 32 * 4 + 2048 * 4;
+  const size_t accb = (size_t)TA * TB * a.TG * 4;       // all-taps flush image (used only when it fits)
+  const size_t acc1 = (size_t)TA * TB * 4;              // per-tap flush image (always fits)
+  const size_t want = stage > acc1 ? stage : acc1;
+  return (accb > want && accb <= 48 * 1024) ? accb : want;
 }
 
 template <typename T>
-static int launch_wgrad2_t(const Wgrad2Args& a, int dt, dim3 grid, int ta16, int tb16, hipStream_t s) {
+static int launch_wgrad2_t(Wgrad2Args a, int dt, dim3 grid, int ta16, int tb16, hipStream_t s) {
   const size_t lds = wgrad2_lds_bytes(a, dt, ta16 * 16, tb16 * 16);
+  a.lds_bytes = (int)lds;
   dim3 block(256);
-#define MMVAE_W2(A_, B_) hipLaunchKernelGGL((wgrad2_kernel<T, A_, B_>), grid, block, lds, s, a)
+  const bool ts = a.ntaps >= 4;
+#define MMVAE_W2(A_, B_) do { if (ts) hipLaunchKernelGGL((wgrad2_kernel<T, A_, B_, true>), grid, block, lds, s, a); \
+                              else hipLaunchKernelGGL((wgrad2_kernel<T, A_, B_, false>), grid, block, lds, s, a); } while (0)
   if (ta16 == 1 && tb16 == 1) MMVAE_W2(1, 1);
   else if (ta16 == 1 && tb16 == 2) MMVAE_W2(1, 2);
   else if (ta16 == 2 && tb16 == 1) MMVAE_W2(2, 1);

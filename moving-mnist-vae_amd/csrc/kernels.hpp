@@ -49,10 +49,10 @@ struct WgradArgs {
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
 
 // ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
-// A tile is up to 128 q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.
+// A tile is up to TP (128, or 64/32 for wgrad on tiny feature maps) q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.
 // Its input patch per segment is PR x PW pixels starting at input (hq0*SI + oh, ow).
-struct TileGeom { int N, Hq, Wq, Hi, Wi, SI, oh, ow, segs, qr, PR, PW, tiles_per_img, ntiles; };
-bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w);
+struct TileGeom { int N, Hq, Wq, Hi, Wi, SI, oh, ow, segs, qr, PR, PW, tiles_per_img, ntiles, TP; };
+bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w, int TP = 128);
 struct Phase2 { TileGeom g; int ph, pw, ntaps, tap0; long w_off; };
 struct Gather2Args {
   const void* x; const void* w; void* y;
@@ -70,8 +70,10 @@ struct Wgrad2Args {
   TileGeom g;
   int Ca, Cb, Cb_valid, ksz, ntaps, TG;
   int sA, sB; int tap_off[25]; float scale;
+  int lds_bytes;           // dynamic LDS given to the block (set by the launcher)
 };
 size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB);
+int wgrad2_taps_per_block(int ta16, int tb16, int ntaps);
 int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s);
 bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
