@@ -1,0 +1,141 @@
+"""Data-parallel path: one process per device, flat-gradient buckets, sum all-reduce, 1/world folded
+into Adam.  CPU part: the exchange logic of GradSync over gloo, world_size 2.  GPU part: two full HIP ranks sharing the
+one test GPU (gloo moves CUDA tensors through the host; on the 8-GPU node the backend is "nccl" = RCCL over xGMI)."""
+import importlib
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+# ---------------------------------------------------------------------------------------------- CPU: exchange logic
+def _cpu_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        M = importlib.import_module("moving-mnist-vae_amd.model")
+        n, dec_off = 1000, 600
+        fake = types.SimpleNamespace(_flat=torch.full((n,), float(rank + 1)), _bnf=torch.full((7,), float(rank)), _sync=None,
+                                     _dec_off=dec_off, _n_params=n, _ensure_flat=lambda: None)
+        sync = M.GradSync(fake)
+        assert fake._sync is sync and sync.world == world
+        assert torch.all(fake._flat == 1.0) and torch.all(fake._bnf == 0.0)           # rank 0's values everywhere
+        G = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        sync.bucket_ready(G, dec_off, n)          # decoder gradients are complete first
+        sync.bucket_ready(G, 0, dec_off)
+        scale = sync.finish(G)
+        expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        assert scale == 1.0 / world
+        assert torch.equal(G, expect)
+        # a bucket that was never announced (e.g. a frozen decoder) is still reduced by finish()
+        G2 = torch.ones(n) * (rank + 1)
+        sync.bucket_ready(G2, dec_off, n)
+        sync.finish(G2)
+        assert torch.all(G2 == 3.0)
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_gradsync_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, 29531, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ---------------------------------------------------------------------------------------------- GPU: two HIP ranks
+def _gpu_worker(rank, world, port, q):
+    try:
+        _init(rank, world, port)
+        from oracle import vae_oracle as O
+        pkg = importlib.import_module("moving-mnist-vae_amd")
+        M = importlib.import_module("moving-mnist-vae_amd.model")
+        dev = torch.device("cuda:0")
+        z, S, N = 32, 64, 8
+        spec = O.state_spec(1, z, 1, S, True)
+        state = O.filled_state(spec, seed=0)
+        args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
+        batches = [O.synthetic_labels(N, S, seed=100 + r).view(N, S * S) for r in range(world)]
+        noise = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(500 + r)
+            noise.append((torch.randn(N, z, 1, 1, generator=g), torch.randn(N, z, generator=g)))
+
+        def fresh(sync):
+            m = M.VAE(1, 32, 1, 2, z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, S, compute_dtype="f32")
+            m.load_state_dict(state if (rank == 0 or not sync) else {k: v * 0 + 1 for k, v in state.items()})  # non-zero ranks start wrong on purpose
+            m.to(dev).train()
+            return m
+
+        # ---- data-parallel step: every rank its own batch, broadcast from rank 0, averaged gradients
+        m = fresh(True)
+        M.GradSync(m)
+        opt = M.FusedAdam(list(m.parameters()))
+        m.injected_eps, m.injected_true_samples = noise[rank][0].to(dev), noise[rank][1].to(dev)
+        pkg.train(m, [batches[rank]], opt, dev, args, data_mean=O.DATA_MEAN, data_std=O.DATA_STD)
+        torch.cuda.synchronize()
+        mine = m._flat.detach().cpu()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        for r in range(1, world):
+            assert torch.equal(gathered[0], gathered[r]), "ranks diverged"
+        if rank == 0:
+            # ---- expected: gradients of each shard computed one after the other on the same weights, averaged, one Adam step
+            grads = []
+            for r in range(world):
+                mr = fresh(False)
+                mr.injected_eps, mr.injected_true_samples = noise[r][0].to(dev), noise[r][1].to(dev)
+                img, tgt = pkg.main.prepare_batch(mr, batches[r], dev, args, O.DATA_MEAN, O.DATA_STD)
+                out = mr(img)
+                loss = mr.loss(tgt, *out, dev, args)[0]
+                loss.backward()
+                grads.append(torch.cat([p.grad.reshape(-1) for p in mr.parameters()]).clone())
+            ref = fresh(False)
+            p0 = ref._flat.detach().clone()
+            gavg = sum(grads) / world
+            # Adam, first step: p - lr * g / (|g| + eps)   (bias-corrected m/sqrt(v) = g/|g|)
+            expect = p0 - 1e-3 * gavg / (gavg.abs() + 1e-8)
+            err = (mine.to(dev) - expect).abs().max().item()
+            assert err < 2e-5, err
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()[-1500:]))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_hip_ranks_average_gradients():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, 29532, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
