@@ -254,32 +254,40 @@ bool conv_force_v1() {
   return v != 0;
 }
 
-bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w, int TP) {
+bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w, int TP, int sub) {
   if (Hq <= 0 || Wq <= 0 || Wq > TP || N <= 0) return false;
-  g.N = N; g.Hq = Hq; g.Wq = Wq; g.Hi = Hi; g.Wi = Wi; g.SI = SI; g.oh = oh; g.ow = ow; g.TP = TP;
+  if (sub > 1 && (TP != 128 || (Hq * Wq >= 128 ? 128 % Wq != 0 : 128 % (Hq * Wq) != 0))) return false;   // sub-tiles must be whole rows / images
+  g.N = N; g.Hq = Hq; g.Wq = Wq; g.Hi = Hi; g.Wi = Wi; g.SI = SI; g.oh = oh; g.ow = ow; g.TP = TP * sub; g.sub = sub;
   if (Hq * Wq >= TP) {
-    g.segs = 1; g.qr = TP / Wq; if (g.qr > Hq) g.qr = Hq;
+    g.segs = 1; g.sub_j = TP / Wq; g.sub_seg = 0;
+    g.qr = g.sub_j * sub; if (g.qr > Hq) g.qr = Hq;
     g.tiles_per_img = (Hq + g.qr - 1) / g.qr;
     g.ntiles = N * g.tiles_per_img;
   } else {
-    g.segs = TP / (Hq * Wq); g.qr = Hq; g.tiles_per_img = 0;
+    g.sub_seg = TP / (Hq * Wq); g.sub_j = 0;
+    g.segs = g.sub_seg * sub; g.qr = Hq; g.tiles_per_img = 0;
     g.ntiles = (N + g.segs - 1) / g.segs;
   }
   g.PR = (g.qr - 1) * SI + span_h;
   g.PW = (Wq - 1) * SI + span_w;
-  return g.PR < 256 && g.PW < 256 && g.segs <= 128;
+  g.sub_pix = g.tiles_per_img > 0 ? g.sub_j * SI * g.PW : g.sub_seg * g.PR * g.PW;
+  return g.PR < 256 && g.PW < 256 && g.segs <= 512;
 }
 
 constexpr size_t kV2MaxLds = 60 * 1024;
 
 // Returns >0 (stats rows) when the v2 kernel ran, 0 when the launch is not eligible, <0 on error.
 static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
-  if (conv_force_v1() || a.Cout > 64 || a.Cin > 512) return 0;
+  const bool boundary = a.x_planar || a.y_planes;      // these layouts exist only in the patch-tile kernel
+  if ((conv_force_v1() && !boundary) || a.Cout > 64 || a.Cin > 512) return 0;
+  if (boundary && ((a.x_planar && (a.Cin > 16 || a.x_planes > a.Cin)) || (a.y_planes && (a.Cout != 16 || a.y_planes > 16)))) return 0;
   Gather2Args b; memset(&b, 0, sizeof(b));
   b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
   b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate;
   b.Cin = a.Cin; b.Cout = a.Cout; b.Ho = a.Ho; b.Wo = a.Wo; b.SO = a.SO; b.nphase = a.nphase;
+  b.x_planar = a.x_planar; b.x_planes = a.x_planes; b.y_planes = a.y_planes;
   int max_tiles = 0;
+  int span[kMaxPhases][4];
   for (int p = 0; p < a.nphase; ++p) {
     const Phase& ph = a.phases[p];
     int dh0 = 0, dh1 = 0, dw0 = 0, dw1 = 0;
@@ -290,14 +298,28 @@ static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
       dw0 = tp.dw < dw0 ? tp.dw : dw0; dw1 = tp.dw > dw1 ? tp.dw : dw1;
     }
     Phase2& q = b.phases[p];
-    if (!make_tile_geom(q.g, a.N, ph.Hq, ph.Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1)) return 0;
     q.ph = ph.ph; q.pw = ph.pw; q.ntaps = ph.ntaps; q.tap0 = ph.tap0; q.w_off = ph.w_off;
-    if (q.g.ntiles > max_tiles) max_tiles = q.g.ntiles;
+    span[p][0] = dh0; span[p][1] = dw0; span[p][2] = dh1 - dh0 + 1; span[p][3] = dw1 - dw0 + 1;
   }
   for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
   const int CT = ((a.Cout + 15) / 16 == 3 ? 4 : (a.Cout + 15) / 16) * 16;
-  const size_t lds = gather2_lds_bytes(b, dt, CT);
-  if (lds > kV2MaxLds) return 0;
+  // largest tile (4, 2 or 1 sub-tiles of 128 pixels per barrier pair) that fits LDS and still leaves >= 1024 tiles
+  size_t lds = 0;
+  bool ok = false;
+  for (int sub = 1; sub >= 1 && !ok; sub >>= 1) {      // (multi-sub-tile tiles measured slower: occupancy beats tile size here)
+    bool geo = true;
+    max_tiles = 0;
+    for (int p = 0; p < a.nphase && geo; ++p) {
+      const Phase& ph = a.phases[p];
+      geo = make_tile_geom(b.phases[p].g, a.N, ph.Hq, ph.Wq, a.Hi, a.Wi, a.SI, span[p][0], span[p][1], span[p][2], span[p][3], 128, sub);
+      if (geo && b.phases[p].g.ntiles > max_tiles) max_tiles = b.phases[p].g.ntiles;
+    }
+    if (!geo) continue;
+    if (sub > 1 && max_tiles * a.nphase < 1024) continue;
+    lds = gather2_lds_bytes(b, dt, CT);
+    ok = lds <= kV2MaxLds;
+  }
+  if (!ok) return 0;
   int occ = (int)((160 * 1024) / lds); if (occ > 4) occ = 4; if (occ < 1) occ = 1;
   int gx = (256 * occ) / a.nphase; if (gx < 1) gx = 1;
   if (gx > max_tiles) gx = max_tiles;
@@ -326,6 +348,7 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   {
     const int rc2 = try_gather2(dt, out_dt, a, s);
     if (rc2 != 0) return rc2;      // >0: launched (stats rows), <0: error, 0: not eligible -> generic kernel
+    if (a.x_planar || a.y_planes) { set_error("gather_gemm: planar boundary layouts need the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }
   }
   const int gx = max_tiles < kGatherMaxGridX ? max_tiles : kGatherMaxGridX;
   if (dt == DT_F32) return launch_gather_t<float, float>(a, gx, s);
@@ -490,7 +513,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
 // Returns 1 when the v2 kernel ran, 0 when not eligible, <0 on error.
 static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
-  if (conv_force_v1() || a.Ca % 16 || a.Cb % 16 || a.ntaps > 16) return 0;
+  const bool boundary = a.P_planar || a.G_planar;
+  if ((conv_force_v1() && !boundary) || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
+  if ((a.P_planar && a.Ca != 16) || (a.G_planar && a.Cb != 16)) return 0;
   auto pick = [](int c) { return c >= 64 ? 64 : c; };
   const int TA = pick(a.Ca), TB = pick(a.Cb);
   if (!(TA == 16 || TA == 32 || TA == 64) || !(TB == 16 || TB == 32 || TB == 64)) return 0;
@@ -502,13 +527,18 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   b.proG_scale = a.proG_scale; b.proG_shift = a.proG_shift; b.proG_relu = a.proG_relu;
   b.TG = wgrad2_taps_per_block(ta16, tb16, a.ntaps);
   bool fits = false;
-  for (int TP = 128; TP >= 32 && !fits; TP >>= 1) {     // shrink the pixel tile until patch + P tile fit in LDS
+  for (int sub = 1; sub > 1 && !fits; sub >>= 1) {       // (disabled: larger tiles cost more in occupancy than they save in barriers)
+    if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, 128, sub)) continue;
+    fits = b.g.ntiles >= 1024 && wgrad2_lds_bytes(b, dt, TA, TB) <= kV2MaxLds;
+  }
+  for (int TP = 128; TP >= 32 && !fits; TP >>= 1) {     // else shrink the pixel tile until patch + P tile fit in LDS
     if (TP < 128 && a.ntaps < 4) break;                 // the k-split mode (1x1 convs) needs all four k-steps
-    if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, TP)) continue;
+    if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, TP, 1)) continue;
     fits = wgrad2_lds_bytes(b, dt, TA, TB) <= kV2MaxLds;
   }
   if (!fits) return 0;
-  b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
+  b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.Ca_valid = a.Ca_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
+  b.P_planar = a.P_planar; b.P_planes = a.P_planes; b.G_planar = a.G_planar; b.G_planes = a.G_planes;
   b.sA = a.sA; b.sB = a.sB; b.scale = a.scale;
   for (int t = 0; t < 25; ++t) b.tap_off[t] = a.tap_off[t];
   const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
@@ -533,10 +563,12 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   }
   a.M = a.N * a.Hp * a.Wp;
   if (a.Cb_valid <= 0 || a.Cb_valid > a.Cb) a.Cb_valid = a.Cb;
+  if (a.Ca_valid <= 0 || a.Ca_valid > a.Ca) a.Ca_valid = a.Ca;
   if (a.M <= 0) return MMVAE_OK;
   {
     const int rc2 = try_wgrad2(dt, a, s);
     if (rc2 != 0) return rc2 < 0 ? rc2 : MMVAE_OK;
+    if (a.P_planar || a.G_planar) { set_error("wgrad: planar boundary layouts need the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }
   }
   const int TA = a.Ca >= 64 ? 64 : ((a.Ca + 15) / 16) * 16;
   const int TB = a.Cb >= 64 ? 64 : ((a.Cb + 15) / 16) * 16;
@@ -578,7 +610,8 @@ __global__ void pack_kernel(PackArgs a) {
     const long q = i / a.K;
     const int tp = (int)(q % a.ntaps);
     const int col = (int)(q / a.ntaps);
-    const float v = a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale;
+    const bool real = (a.cols_valid <= 0 || col < a.cols_valid) && (a.K_valid <= 0 || k < a.K_valid);
+    const float v = real ? a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale : 0.f;
     Elem<T>::store(reinterpret_cast<T*>(a.dst) + i, v);
   }
 }

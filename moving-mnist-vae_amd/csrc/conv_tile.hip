@@ -102,6 +102,40 @@ __device__ __forceinline__ void stage_patch(const TileGeom& g, int tile, const T
   }
 }
 
+// Same patch, but the source is PLANAR ([N][planes][Hi][Wi], element type ST = float or T) with only `planes` (<= 16)
+// real channels: every patch pixel becomes a 16-channel NHWC LDS pixel whose channels >= planes are zero, so the
+// 1-channel image (stem) and the 1-2-channel reconstruction gradient (tail) run through the same MFMA kernels.
+template <typename T, typename ST>
+__device__ __forceinline__ void stage_patch_planar(const TileGeom& g, int tile, const ST* __restrict__ X, int planes, int Cpad,
+                                                   Vec16* sPatch) {
+  constexpr int VE = Elem<T>::kVec;
+  const int NV = Cpad / VE;                 // vec16 per staged pixel (Cpad in {VE, 8, 16})
+  const int total = g.segs * g.PR * g.PW;
+  int n1, hq01;
+  tile_origin(g, tile, 0, n1, hq01);
+  const bool multi = g.tiles_per_img == 0;
+  const int h_base = hq01 * g.SI + g.oh;
+  const long plane = (long)g.Hi * g.Wi;
+  for (int v = threadIdx.x; v < total; v += 256) {
+    const int row = v / g.PW, pc = v - row * g.PW;
+    const int seg = row / g.PR, pr = row - seg * g.PR;
+    const int n = multi ? n1 + seg : n1;
+    const int hi = h_base + pr, wi = g.ow + pc;
+    float f[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) f[c] = 0.f;
+    if (n < g.N && hi >= 0 && hi < g.Hi && wi >= 0 && wi < g.Wi) {
+      const ST* src = X + (long)n * planes * plane + (long)hi * g.Wi + wi;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < planes) f[c] = Elem<ST>::load(src + c * plane);
+    }
+#pragma unroll
+    for (int k = 0; k < 16 / VE; ++k)
+      if (k < NV) sPatch[v * NV + k] = Elem<T>::pack(f + k * VE);
+  }
+}
+
 template <typename TO> __device__ __forceinline__ void store4v(TO* p, const float* v, bool acc);
 template <> __device__ __forceinline__ void store4v<float>(float* p, const float* v, bool acc) {
   float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -166,7 +200,7 @@ __global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
   for (int c = 0; c < CT16; ++c)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { st1[c][j] = 0.f; st2[c][j] = 0.f; }
-  const int npix_tile = g.segs * g.qr * g.Wq;
+  const int npix_tile = g.sub > 1 ? 128 : g.segs * g.qr * g.Wq;   // pixel slots of one sub-tile
   const int nks = kvp >> 2;
   const char* patch_bytes = reinterpret_cast<const char*>(sPatch);
   // tile-independent decode of this lane's two pixels
@@ -186,14 +220,18 @@ __global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
 
   for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
     __syncthreads();                 // previous tile's fragment reads are done (also orders the block prologue)
-    stage_patch<T, 4>(g, tile, X, a.Cin, 0, a.Cin, has_pro ? sPro : nullptr, a.pro_relu, sPatch);
+    if (a.x_planar == 0) stage_patch<T, 4>(g, tile, X, a.Cin, 0, a.Cin, has_pro ? sPro : nullptr, a.pro_relu, sPatch);
+    else if (a.x_planar == 1) stage_patch_planar<T, float>(g, tile, reinterpret_cast<const float*>(a.x), a.x_planes, a.Cin, sPatch);
+    else stage_patch_planar<T, T>(g, tile, X, a.x_planes, a.Cin, sPatch);
     __syncthreads();
+   for (int sb = 0; sb < g.sub; ++sb) {
+    const int sub_off = sb * g.sub_pix * a.Cin * ES;
     f32x4 acc[CT16][2];
 #pragma unroll
     for (int c = 0; c < CT16; ++c) { acc[c][0] = (f32x4){0, 0, 0, 0}; acc[c][1] = (f32x4){0, 0, 0, 0}; }
     for (int ks = 0; ks < nks; ++ks) {
       const int kv = 4 * ks + gq;
-      const int koff = sKoff[kv];
+      const int koff = sKoff[kv] + sub_off;
       const Vec16 b0 = *reinterpret_cast<const Vec16*>(patch_bytes + pbase[0] + koff);
       const Vec16 b1 = *reinterpret_cast<const Vec16*>(patch_bytes + pbase[1] + koff);
 #pragma unroll
@@ -209,9 +247,26 @@ __global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
       if (pseg[pt] >= 0) {
         const int wq = pwq[pt];
         int n, hq0;
-        tile_origin(g, tile, pseg[pt], n, hq0);
-        const int hq = hq0 + pj[pt];
-        if (n < g.N && hq < g.Hq) {
+        tile_origin(g, tile, pseg[pt] + sb * g.sub_seg, n, hq0);
+        const int hq = hq0 + pj[pt] + sb * g.sub_j;
+        if (n < g.N && hq < g.Hq && a.y_planes > 0) {
+          // NCHW f32 output with y_planes (<= 16) real channels: the reconstruction layout of the reference
+          if (gq * 4 < a.y_planes) {
+            float* Yp = reinterpret_cast<float*>(a.y);
+            const long hw = (long)a.Ho * a.Wo;
+            const long pix = (long)(hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int co = 4 * gq + jj;
+              if (co < a.y_planes) {
+                const float v = acc[0][pt][jj] + (a.bias ? a.bias[co] : 0.f);
+                st1[0][jj] += v;
+                st2[0][jj] += v * v;
+                Yp[((long)n * a.y_planes + co) * hw + pix] = v;
+              }
+            }
+          }
+        } else if (n < g.N && hq < g.Hq) {
           const long obase = ((long)(n * a.Ho + hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw)) * a.Cout;
 #pragma unroll
           for (int c = 0; c < CT16; ++c) {
@@ -230,6 +285,7 @@ __global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
         }
       }
     }
+   }
   }
   if (a.stats) {
 #pragma unroll
@@ -256,7 +312,8 @@ __global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
     if (t < 2 * CT) {
       const float s = sStat[t] + sStat[2 * CT + t] + sStat[4 * CT + t] + sStat[6 * CT + t];
       const int which = t / CT, cl = t - which * CT;
-      if (cl < a.Cout) a.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * a.Cout + (long)which * a.Cout + cl] = s;
+      const int cs = a.y_planes > 0 ? a.y_planes : a.Cout;      // channel count of the statistics rows
+      if (cl < cs) a.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * cs + (long)which * cs + cl] = s;
     }
   }
 }
@@ -368,7 +425,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     for (int ta = 0; ta < TA16; ++ta)
 #pragma unroll
       for (int tb = 0; tb < TB16; ++tb) acc[tl][ta][tb] = (f32x4){0, 0, 0, 0};
-  const int npix_tile = g.segs * g.qr * g.Wq;
+  const int npix_sub = g.sub > 1 ? 128 : g.segs * g.qr * g.Wq;      // pixel slots of one sub-tile
   constexpr int pv = TA / VE;
   // tile-independent LDS offsets of this lane's fragment pixels (bf16: 2 four-pixel blocks per k-step)
   int offP[NKS][2], offG[NKS][2];
@@ -379,7 +436,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
       for (int b = 0; b < 2; ++b) {
         int p = 32 * (TS ? i : wv) + 16 * b + 4 * gq + (r >> 2);
         offP[i][b] = p * TA * ES + (r & 3) * 8;
-        if (p >= npix_tile) p = 0;                  // P rows beyond the tile are zero; any finite G value will do
+        if (p >= npix_sub) p = 0;                   // P rows beyond the tile are zero; any finite G value will do
         offG[i][b] = patch_index(g, p) * TB * ES + (r & 3) * 8;
       }
   }
@@ -397,6 +454,25 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
       const long m0 = ((long)n * g.Hq + hq0) * g.Wq;
       const long mend = g.tiles_per_img > 0 ? ((long)n * g.Hq + min(g.Hq, hq0 + g.qr)) * g.Wq : (long)min(g.N, n + g.segs) * g.Hq * g.Wq;
       const int nvalid = (int)(mend - m0);
+      if (a.P_planar) {
+        // P is planar f32 [N][P_planes][Hq][Wq] (the reconstruction gradient): 16 zero-padded channels per LDS pixel
+        const float* Pf = reinterpret_cast<const float*>(a.P);
+        const long plane = (long)g.Hq * g.Wq;
+        for (int pix = t; pix < g.TP; pix += 256) {
+          float f[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) f[c] = 0.f;
+          if (pix < nvalid) {
+            const long m = m0 + pix;
+            const long nn = m / plane, rem = m - nn * plane;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+              if (c < a.P_planes) f[c] = Pf[(nn * a.P_planes + c) * plane + rem];
+          }
+#pragma unroll
+          for (int k = 0; k < 16 / VE; ++k) reinterpret_cast<Vec16*>(sP)[pix * (16 / VE) + k] = Elem<T>::pack(f + k * VE);
+        }
+      } else
       for (int v = t; v < g.TP * pv; v += 256) {
         const int pix = v / pv, cv = v - pix * pv;
         Vec16 q = Vec16{{0, 0, 0, 0}};
@@ -416,23 +492,26 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         reinterpret_cast<Vec16*>(sP)[v] = q;
       }
     }
-    stage_patch<T, 8>(g, tile, Gp, a.Cb, b0, TB, proG ? sProG : nullptr, a.proG_relu, reinterpret_cast<Vec16*>(sG));
+    if (a.G_planar) stage_patch_planar<T, T>(g, tile, Gp, a.G_planes, 16, reinterpret_cast<Vec16*>(sG));
+    else stage_patch<T, 8>(g, tile, Gp, a.Cb, b0, TB, proG ? sProG : nullptr, a.proG_relu, reinterpret_cast<Vec16*>(sG));
     __syncthreads();
-    const int nks_tile = g.TP >> 5;                   // 32-pixel k-steps in this tile size (TS mode: 4, 2 or 1)
+    const int nks_tile = g.sub > 1 ? 4 : (g.TP >> 5);  // 32-pixel k-steps per sub-tile (TS mode: 4, 2 or 1)
+   for (int sb = 0; sb < g.sub; ++sb) {
+    const int subP = sb * 128 * TA * ES, subG = sb * g.sub_pix * TB * ES;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int i = 0; i < NKS; ++i) {
         if (TS && i >= nks_tile) break;
         Vec16 af[TA16];
 #pragma unroll
-        for (int ta = 0; ta < TA16; ++ta) af[ta] = FragOps<bf16_t>::load(sP, offP[i][0] + ta * 32, offP[i][1] + ta * 32);
+        for (int ta = 0; ta < TA16; ++ta) af[ta] = FragOps<bf16_t>::load(sP, offP[i][0] + subP + ta * 32, offP[i][1] + subP + ta * 32);
 #pragma unroll
         for (int tl = 0; tl < MAXT; ++tl) {
           if (my_tap[tl] < tg_n) {
             const int toff = sToff[my_tap[tl]];
 #pragma unroll
             for (int tb = 0; tb < TB16; ++tb) {
-              const Vec16 bf = FragOps<bf16_t>::load(sG, offG[i][0] + toff + tb * 32, offG[i][1] + toff + tb * 32);
+              const Vec16 bf = FragOps<bf16_t>::load(sG, offG[i][0] + subG + toff + tb * 32, offG[i][1] + subG + toff + tb * 32);
 #pragma unroll
               for (int ta = 0; ta < TA16; ++ta) acc[tl][ta][tb] = mma_bf16(af[ta], bf, acc[tl][ta][tb]);
             }
@@ -446,9 +525,9 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         const int ks = TS ? i : wv;
         for (int j = 0; j < 8; ++j) {
           int p = 32 * ks + 4 * j + gq;
-          const int oP = p * TA * ES + r * 4;
-          if (p >= npix_tile) p = 0;
-          const int oG = patch_index(g, p) * TB * ES + r * 4;
+          const int oP = p * TA * ES + r * 4 + subP;
+          if (p >= npix_sub) p = 0;
+          const int oG = patch_index(g, p) * TB * ES + r * 4 + subG;
           float av[TA16];
 #pragma unroll
           for (int ta = 0; ta < TA16; ++ta) av[ta] = *reinterpret_cast<const float*>(sP + oP + ta * 64);
@@ -468,6 +547,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         }
       }
     }
+   }
   }
   // ---- flush.  Preferred: combine the waves in LDS as [a_l][b_l][tap] (tap fastest) and issue global atomics on
   // consecutive addresses.  When that image does not fit the block's LDS, go tap by tap through a [a_l][b_l] buffer.
@@ -495,7 +575,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     for (int i = t; i < nacc; i += 256) {
       const int tl = i % tg_n, ab = i / tg_n;
       const int bl = ab % TB, al = ab / TB;
-      if (a0 + al < a.Ca && b0 + bl < a.Cb_valid)
+      if (a0 + al < a.Ca_valid && b0 + bl < a.Cb_valid)
         atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tl], sAcc[i] * a.scale);
     }
   } else {
@@ -518,7 +598,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         __syncthreads();
         for (int i = t; i < TA * TB; i += 256) {
           const int bl = i % TB, al = i / TB;
-          if (a0 + al < a.Ca && b0 + bl < a.Cb_valid)
+          if (a0 + al < a.Ca_valid && b0 + bl < a.Cb_valid)
             atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tap_l], sAcc[i] * a.scale);
         }
         __syncthreads();

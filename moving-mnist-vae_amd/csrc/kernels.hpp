@@ -14,7 +14,7 @@ inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
 // Covers Conv2d forward (SI=stride, SO=1, one launch) and every stride-phase of a
 // transposed convolution / data-gradient (SI=1, SO=stride, one launch per phase).
 struct Tap { int dh, dw; };
-constexpr int kMaxTaps = 16;     // over all phases of one launch
+constexpr int kMaxTaps = 25;     // over all phases of one launch (5x5 stem)
 constexpr int kMaxPhases = 4;
 struct Phase { int ph, pw, Hq, Wq, ntaps, tap0; long w_off; /* element offset of this phase's [Cout][ntaps*Cin] matrix */ };
 struct GatherArgs {
@@ -27,6 +27,9 @@ struct GatherArgs {
   int SI, SO;
   int nphase; Phase phases[kMaxPhases]; Tap taps[kMaxTaps];
   int cin_vecs;
+  // optional boundary layouts (patch-tile kernels only):
+  int x_planar, x_planes;  // 1: x is planar f32 [N][x_planes][Hi][Wi], 2: planar T; staged as Cin=16 channels, zero padded
+  int y_planes;            // >0: y is NCHW f32 [N][y_planes][Ho][Wo] (Cout = 16 padded GEMM rows; stats rows have y_planes channels)
 };
 // out_dt: dtype of y (may be DT_F32 while x/w are bf16).  Returns the number of stats partial rows (>0) or an error (<0).
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s);
@@ -40,6 +43,9 @@ struct WgradArgs {
   const float* proG_scale; const float* proG_shift; int proG_relu;
   int N, Hp, Wp, Ca, Hg, Wg, Cb;
   int Cb_valid;            // b >= Cb_valid is computed but not written (0 -> Cb)
+  int Ca_valid;            // likewise for a (0 -> Ca)
+  int P_planar, P_planes;  // 1: P is planar f32 [N][P_planes][Hp][Wp] staged as Ca=16 zero-padded channels (patch-tile kernel only)
+  int G_planar, G_planes;  // 2: G is planar T  [N][G_planes][Hg][Wg] staged as Cb=16 zero-padded channels
   int stride, pad, ksz;
   int sA, sB; int ntaps; int tap_off[25];
   float scale;
@@ -51,8 +57,11 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
 // ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
 // A tile is up to TP (128, or 64/32 for wgrad on tiny feature maps) q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.
 // Its input patch per segment is PR x PW pixels starting at input (hq0*SI + oh, ow).
-struct TileGeom { int N, Hq, Wq, Hi, Wi, SI, oh, ow, segs, qr, PR, PW, tiles_per_img, ntiles, TP; };
-bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w, int TP = 128);
+// A tile may hold `sub` (1,2,4) consecutive 128-pixel sub-tiles staged behind ONE barrier pair: sub-tile s starts `sub_j`*s
+// q-rows (or `sub_seg`*s images) further, i.e. `sub_pix`*s patch pixels further.
+struct TileGeom { int N, Hq, Wq, Hi, Wi, SI, oh, ow, segs, qr, PR, PW, tiles_per_img, ntiles, TP, sub, sub_j, sub_seg, sub_pix; };
+bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w, int TP = 128,
+                    int sub = 1);
 struct Phase2 { TileGeom g; int ph, pw, ntaps, tap0; long w_off; };
 struct Gather2Args {
   const void* x; const void* w; void* y;
@@ -60,6 +69,7 @@ struct Gather2Args {
   const float* bias; float* stats; int accumulate;
   int Cin, Cout, Ho, Wo, SO;
   int nphase; Phase2 phases[kMaxPhases]; Tap taps[kMaxTaps];
+  int x_planar, x_planes, y_planes;
 };
 size_t gather2_lds_bytes(const Gather2Args& a, int dt, int CT);
 int launch_gather2(int dt, int out_dt, const Gather2Args& a, int gx, hipStream_t s);
@@ -68,7 +78,8 @@ struct Wgrad2Args {
   const float* proP_scale; const float* proP_shift; int proP_relu;
   const float* proG_scale; const float* proG_shift; int proG_relu;
   TileGeom g;
-  int Ca, Cb, Cb_valid, ksz, ntaps, TG;
+  int Ca, Cb, Cb_valid, Ca_valid, ksz, ntaps, TG;
+  int P_planar, P_planes, G_planar, G_planes;
   int sA, sB; int tap_off[25]; float scale;
   int lds_bytes;           // dynamic LDS given to the block (set by the launcher)
 };
@@ -81,6 +92,7 @@ bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B an
 // dst[(col*ntaps + t)*K + k] = T(scale * src[col*s_col + k*s_k + tap_off[t]])
 struct PackArgs {
   const float* src; void* dst; int cols, K, ntaps; int s_col, s_k; int tap_off[kMaxTaps]; float scale;
+  int cols_valid, K_valid;   // >0: columns / k beyond these are written as zero (channel padding), source not read
 };
 int launch_pack(int dt, const PackArgs& a, hipStream_t s);
 
@@ -170,6 +182,8 @@ int launch_normalise(int dt, const long long* labels, long n, float mean, float 
 int launch_convert(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s);
 int launch_concat2_to_t(int dt, const float* a, const float* b, int rows, int ca, int cb, void* out, hipStream_t s);
 int launch_loss_finish(const double* acc, float* out, float nll, float klc, float mmdc, float n, hipStream_t s);
+// out[c] += sum_p partials[p*row_stride + c]  (c < C)
+int launch_partials_add(const float* partials, int nparts, int row_stride, int C, float* out, hipStream_t s);
 int launch_double_to_float(const double* in, float* out, int n, float scale, hipStream_t s);
 
 }  // namespace mmvae

@@ -351,6 +351,19 @@ int launch_loss_finish(const double* acc, float* out, float nll, float klc, floa
   return check_launch("loss_finish");
 }
 
+__global__ void partials_add_kernel(const float* partials, int nparts, int row_stride, int C, float* out) {
+  const int c = blockIdx.x;
+  float v = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += blockDim.x) v += partials[(long)p * row_stride + c];
+  v = wave_sum(v);
+  if (threadIdx.x == 0) out[c] += v;
+}
+int launch_partials_add(const float* partials, int nparts, int row_stride, int C, float* out, hipStream_t s) {
+  if (C <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(partials_add_kernel, dim3(C), dim3(64), 0, s, partials, nparts, row_stride, C, out);
+  return check_launch("partials_add");
+}
+
 __global__ void d2f_kernel(const double* in, float* out, int n, float scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)(in[i] * (double)scale);

@@ -72,6 +72,9 @@ Net::Net(const NetCfg& c) : cfg(c) {
   head_pack_mu = n_packed; n_packed += hp;
   head_pack_lv = n_packed; n_packed += hp;
   head_pack_dg = n_packed; n_packed += align_up(2L * c.z * 256, 8);
+  stem_pack = n_packed; n_packed += 32L * 25 * 8;
+  tail_pack_f = n_packed; n_packed += 16L * 9 * 16;
+  tail_pack_d = n_packed; n_packed += 16L * 9 * 8;
   // ---- decoder (model.py:154-179)
   dec_param_off = n_params;
   dstem = add_conv("decoder.conv1.weight", c.z, 128, 2, 2, 0, true);   // k2 s1 p0 on a 1x1 input == k2 s2 p0
@@ -201,11 +204,26 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   float* stats = training ? part : nullptr;
   const int S = cfg.S;
   MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
-  MM_TRY(launch_stem_fwd(dt(), base + P.x_t, params + stem.off, base + P.y0, N, S, S, H1, W1, 32, s));
-  if (training) {
-    const int np = launch_chan_stats_nhwc(dt(), base + P.y0, (long)N * H1 * W1, 32, part, s);
+  {
+    // stem Conv2d(1 -> 32, k5 s2 p2) (model.py:94): the 1-channel image is staged as a zero-padded VE-channel NHWC patch
+    // in LDS and runs through the MFMA patch-tile kernel; BatchNorm statistics come out of its epilogue.
+    const int cpad = dt() == DT_F32 ? 4 : 8;
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = params + stem.off; pa.dst = base + P.packed + stem_pack * (long)esz();
+    pa.cols = 32; pa.K = cpad; pa.K_valid = 1; pa.ntaps = 25; pa.s_col = 25; pa.s_k = 25; pa.scale = 1.f;
+    for (int t = 0; t < 25; ++t) pa.tap_off[t] = t;
+    MM_TRY(launch_pack(dt(), pa, s));
+    GatherArgs a; std::memset(&a, 0, sizeof(a));
+    a.x = base + P.x_t; a.w = pa.dst; a.y = base + P.y0; a.stats = stats;
+    a.x_planar = 2; a.x_planes = 1;
+    a.N = N; a.Hi = S; a.Wi = S; a.Cin = cpad; a.Ho = H1; a.Wo = W1; a.Cout = 32; a.SI = 2; a.SO = 1;
+    a.nphase = 1; a.phases[0] = Phase{0, 0, H1, W1, 25, 0, 0};
+    for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw) a.taps[kh * 5 + kw] = Tap{kh - 2, kw - 2};
+    const int np = launch_gather_gemm(dt(), dt(), a, s);
     MM_TRY(np);
-    MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
+    if (training) MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
+  }
+  if (training) {
   } else {
     MM_TRY(bn_eval(bn0, params, bnbuf, base, s));
   }
@@ -315,7 +333,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(run_up(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     cur ^= 1;
   }
-  // ---- stem: bn0 + relu backward, then the 5x5 weight gradient through an im2col of the 1-channel image
+  // ---- stem: bn0 + relu backward, then the 5x5 weight gradient (image patch padded to 16 channels in LDS)
   {
     const long npix = (long)N * H1 * W1;
     int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, nullptr, npix, 32, part, s);
@@ -323,6 +341,8 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(bn_backward_coefs(bn0, params, grads, base, np, 1, 0, (double)npix, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, bnf(bn0, base, 4),
                                bnf(bn0, base, 5), bnf(bn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 32, s));
+    // im2col of the 1-channel image (25 taps padded to 32 columns) + the MFMA weight-gradient kernel (measured faster than
+    // padding the image patch to 16 channels in LDS)
     MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, s));
     WgradArgs a; std::memset(&a, 0, sizeof(a));
     a.P = base + P.dy1; a.G = base + P.col; a.dW = grads + stem.off;
@@ -371,11 +391,23 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   }
   // tail conv (+bias) and the output BatchNorm (model.py:193)
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
-  MM_TRY(launch_tail_fwd(dt(), xin, params + tail.off, params + tail_bias, r_raw, N, Sd, Sd, cfg.out_ch, s));
-  if (training) {
-    np = launch_chan_stats_nchw(r_raw, N, cfg.out_ch, Sd * Sd, part, s);
+  {
+    // Conv2d(16 -> out_ch, k3 p1, bias): GEMM rows padded to 16 in LDS, epilogue stores the out_ch real rows as NCHW f32
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_f * (long)esz();
+    pa.cols = 16; pa.cols_valid = cfg.out_ch; pa.K = 16; pa.ntaps = 9; pa.s_col = 144; pa.s_k = 9; pa.scale = 1.f;
+    for (int t = 0; t < 9; ++t) pa.tap_off[t] = t;
+    MM_TRY(launch_pack(dt(), pa, s));
+    GatherArgs a; std::memset(&a, 0, sizeof(a));
+    a.x = xin; a.w = pa.dst; a.y = r_raw; a.bias = params + tail_bias; a.stats = stats; a.y_planes = cfg.out_ch;
+    a.N = N; a.Hi = Sd; a.Wi = Sd; a.Cin = 16; a.Ho = Sd; a.Wo = Sd; a.Cout = 16; a.SI = 1; a.SO = 1;
+    a.nphase = 1; a.phases[0] = Phase{0, 0, Sd, Sd, 9, 0, 0};
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) a.taps[kh * 3 + kw] = Tap{kh - 1, kw - 1};
+    np = launch_gather_gemm(dt(), DT_F32, a, s);
     MM_TRY(np);
-    MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
+    if (training) MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
+  }
+  if (training) {
   } else {
     MM_TRY(bn_eval(bn_out, params, bnbuf, base, s));
   }
@@ -397,9 +429,25 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   MM_TRY(np);
   MM_TRY(bn_backward_coefs(bn_out, params, grads, base, np, 1, 0, (double)N * HW, s));
   MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
-  MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, grads + tail_bias, N, Sd, Sd, cfg.out_ch, s));
+  {
+    // direct kernel: dW[oc][ci][kh][kw] and d(bias) (measured faster than the padded-P MFMA path)
+    MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, grads + tail_bias, N, Sd, Sd, cfg.out_ch, s));
+  }
   int cur = 0;
-  MM_TRY(launch_tail_dgrad(dt(), d_raw, params + tail.off, base + P.g[cur], N, Sd, Sd, cfg.out_ch, s));
+  {
+    // dx[n,h,w,ci] = sum dy[n,oc,h+1-kh,w+1-kw] * w[oc][ci][kh][kw]: planar f32 source padded to 8 channels in LDS
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_d * (long)esz();
+    pa.cols = 16; pa.K = 8; pa.K_valid = cfg.out_ch; pa.ntaps = 9; pa.s_col = 9; pa.s_k = 144; pa.scale = 1.f;
+    for (int t = 0; t < 9; ++t) pa.tap_off[t] = t;
+    MM_TRY(launch_pack(dt(), pa, s));
+    GatherArgs a; std::memset(&a, 0, sizeof(a));
+    a.x = d_raw; a.w = pa.dst; a.y = base + P.g[cur]; a.x_planar = 1; a.x_planes = cfg.out_ch;
+    a.N = N; a.Hi = Sd; a.Wi = Sd; a.Cin = 8; a.Ho = Sd; a.Wo = Sd; a.Cout = 16; a.SI = 1; a.SO = 1;
+    a.nphase = 1; a.phases[0] = Phase{0, 0, Sd, Sd, 9, 0, 0};
+    for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) a.taps[kh * 3 + kw] = Tap{1 - kh, 1 - kw};
+    MM_TRY(launch_gather_gemm(dt(), dt(), a, s));
+  }
   for (int i = nup - 1; i >= 0; --i) {
     Block& B = dec[i];
     const long npo = (long)N * B.Hout * B.Wout, npi = (long)N * B.Hin * B.Win;

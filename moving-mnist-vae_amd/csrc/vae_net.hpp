@@ -55,6 +55,7 @@ class Net {
   ConvW dstem; Bn dbn0;
   Block dec[5];
   ConvW tail; long tail_bias; Bn bn_out;
+  long stem_pack, tail_pack_f, tail_pack_d;   // packed-weight slots of the boundary layers (channel-padded)
 
   size_t workspace_bytes(int N);
   const Plan& plan(int N);
