@@ -346,6 +346,23 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   if (ntap > kMaxTaps) { set_error("gather_gemm: %d taps > %d", ntap, kMaxTaps); return MMVAE_ERR_UNSUPPORTED; }
   if (max_tiles <= 0) return 1;
   {
+    // thin layers: barrier-free streaming kernel (weights in LDS, pixels straight from global memory)
+    static const int g3_maxk = [] { const char* e = getenv("MMVAE_GATHER3_MAXK"); return e ? atoi(e) : 160; }();
+    static const int g3_dbg = [] { const char* e = getenv("MMVAE_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = g3_dbg;
+    int maxk = 0;
+    for (int p = 0; p < a.nphase; ++p) if (a.phases[p].ntaps * a.Cin > maxk) maxk = a.phases[p].ntaps * a.Cin;
+    const bool fits32 = (long)a.N * a.Hi * a.Wi * a.Cin < (1L << 31) && (long)a.N * a.Ho * a.Wo * a.Cout < (1L << 31);   // 32-bit element offsets
+    if (!conv_force_v1() && !a.x_planar && !a.y_planes && !a.bias && out_dt == dt && a.Cout <= 64 && maxk <= g3_maxk && fits32) {
+      int ct16 = (a.Cout + 15) / 16; if (ct16 == 3) ct16 = 4;
+      if (gather3_lds_bytes(a, dt, ct16 * 16) <= kV2MaxLds) {
+        long wt = 0;
+        for (int p = 0; p < a.nphase; ++p) { const long m = (long)a.N * a.phases[p].Hq * a.phases[p].Wq; if ((m + 31) / 32 > wt) wt = (m + 31) / 32; }
+        long gx3 = (wt + 3) / 4; if (gx3 > 2048 / a.nphase) gx3 = 2048 / a.nphase; if (gx3 < 1) gx3 = 1;
+        if (gx3 > kGatherMaxGridX) gx3 = kGatherMaxGridX;
+        return launch_gather3(dt, out_dt, a, (int)gx3, s);
+      }
+    }
     const int rc2 = try_gather2(dt, out_dt, a, s);
     if (rc2 != 0) return rc2;      // >0: launched (stats rows), <0: error, 0: not eligible -> generic kernel
     if (a.x_planar || a.y_planes) { set_error("gather_gemm: planar boundary layouts need the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }

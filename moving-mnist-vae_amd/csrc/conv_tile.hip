@@ -650,3 +650,220 @@ int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int
 }
 
 }  // namespace mmvae
+
+namespace mmvae {
+
+// ============================================================================ gather3: barrier-free streaming gather
+// For thin layers (small K, small Cout) LDS staging of the input is pure overhead: no wave shares its pixels with
+// another, only halos overlap and those are served by L1/L2.  Each wave owns 32 output pixels per iteration, loads its
+// MFMA B-fragments (8 consecutive channels of one tap per lane) straight from global memory into registers, and reads
+// the A-fragments from a read-only LDS copy of the phase's weight matrix (filled once per block; the only barrier).
+// These launches are bound by index arithmetic, not by memory (measured: 0.32 of 0.62 ms remain with loads and stores
+// disabled), so the address math is stripped down: power-of-two pixel decode by shifts, one LDS int4 per k-vector with
+// the precomputed element offset and tap displacement, 32-bit element offsets.
+// LDS carve: [weights: CT rows x (kvp+1) vec][sK: kvp int4][sPro: 1024 floats][sStat: 8*CT floats]
+// NKS > 0: the number of 4-k-vector steps is a compile-time constant (fully unrolled, every load of a wave-tile in
+// flight at once); NKS == 0: runtime loop.
+template <typename T, typename TO, int CT16, int NKS>
+__global__ __launch_bounds__(256) void gather3_kernel(GatherArgs a) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int CT = CT16 * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const Phase P = a.phases[blockIdx.z];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, r = lane & 15;
+  const int cin_vecs = a.cin_vecs;
+  const int kvecs = P.ntaps * cin_vecs;
+  const int kvp = (kvecs + 3) & ~3;
+  const int wrow = kvp + 1;
+  Vec16* sW = reinterpret_cast<Vec16*>(smem);
+  int4* sK = reinterpret_cast<int4*>(sW + CT * wrow);
+  float* sPro = reinterpret_cast<float*>(sK + kvp);
+  float* sStat = sPro + 1024;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ Wt = reinterpret_cast<const T*>(a.w) + P.w_off;
+  TO* __restrict__ Y = reinterpret_cast<TO*>(a.y);
+  const bool has_pro = a.pro_scale != nullptr;
+  for (int v = t; v < CT * kvp; v += 256) {
+    const int row = v / kvp, kv = v - row * kvp;
+    sW[row * wrow + kv] = (kv < kvecs && row < a.Cout) ? *reinterpret_cast<const Vec16*>(Wt + ((long)row * kvecs + kv) * VE) : Vec16{{0, 0, 0, 0}};
+  }
+  for (int v = t; v < kvp; v += 256) {
+    int4 e = make_int4(0, 1 << 28, 1 << 28, 0);       // padding k-vectors: displacement far out of range -> zero operand
+    if (v < kvecs) {
+      const int tap = v / cin_vecs, c0 = (v - tap * cin_vecs) * VE;
+      const Tap tp = a.taps[P.tap0 + tap];
+      e = make_int4((tp.dh * a.Wi + tp.dw) * a.Cin + c0, tp.dh, tp.dw, c0);
+    }
+    sK[v] = e;
+  }
+  if (has_pro) for (int i = t; i < a.Cin; i += 256) { sPro[i] = a.pro_scale[i]; sPro[512 + i] = a.pro_shift[i]; }
+  __syncthreads();
+
+  float st1[CT16][4], st2[CT16][4];
+#pragma unroll
+  for (int c = 0; c < CT16; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st1[c][j] = 0.f; st2[c][j] = 0.f; }
+  const int HqWq = P.Hq * P.Wq;
+  const int M = a.N * HqWq;
+  const int nwt = (M + 31) >> 5;
+  const int nks = kvp >> 2;
+  const int sh_w = (P.Wq & (P.Wq - 1)) == 0 ? __builtin_ctz(P.Wq) : -1;       // power-of-two fast path
+  const int sh_hw = (HqWq & (HqWq - 1)) == 0 ? __builtin_ctz(HqWq) : -1;
+  const unsigned uHi = (unsigned)a.Hi, uWi = (unsigned)a.Wi;
+  const int img = a.Hi * a.Wi;
+
+  for (int wt = blockIdx.x * 4 + wv; wt < nwt; wt += gridDim.x * 4) {
+    int xoff[2], ph0[2], pw0[2], yoff[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int m = wt * 32 + 16 * pt + r;
+      int n, hq, wq;
+      if (sh_w >= 0 && sh_hw >= 0) { n = m >> sh_hw; const int rem = m & (HqWq - 1); hq = rem >> sh_w; wq = rem & (P.Wq - 1); }
+      else { n = m / HqWq; const int rem = m - n * HqWq; hq = rem / P.Wq; wq = rem - hq * P.Wq; }
+      ph0[pt] = hq * a.SI;
+      pw0[pt] = wq * a.SI;
+      xoff[pt] = (n * img + ph0[pt] * a.Wi + pw0[pt]) * a.Cin;
+      yoff[pt] = ((n * a.Ho + hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw)) * a.Cout;
+      if (m >= M) ph0[pt] = 1 << 28;                 // every tap lands out of range -> zero operand, no store
+    }
+    f32x4 acc[CT16][2];
+#pragma unroll
+    for (int c = 0; c < CT16; ++c) { acc[c][0] = (f32x4){0, 0, 0, 0}; acc[c][1] = (f32x4){0, 0, 0, 0}; }
+    auto kstep = [&](int ks) {
+      const int kv = 4 * ks + gq;
+      const int4 e = sK[kv];
+      Vec16 b[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        // branch-free: always load (from offset 0 when the tap is out of range), then select zero
+        const bool ok = (unsigned)(ph0[pt] + e.y) < uHi && (unsigned)(pw0[pt] + e.z) < uWi;
+        const unsigned off = ok ? (unsigned)(xoff[pt] + e.x) : 0u;
+        Vec16 v = *reinterpret_cast<const Vec16*>(X + off);
+        if (has_pro) {                                  // uniform branch
+          float f[VE];
+          Elem<T>::unpack(v, f);
+#pragma unroll
+          for (int j = 0; j < VE; ++j) {
+            const float x = f[j] * sPro[e.w + j] + sPro[512 + e.w + j];
+            f[j] = a.pro_relu ? fmaxf(x, 0.f) : x;
+          }
+          v = Elem<T>::pack(f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[pt].w[q] = ok ? v.w[q] : 0u;
+      }
+#pragma unroll
+      for (int c = 0; c < CT16; ++c) {
+        const Vec16 af = sW[(16 * c + r) * wrow + kv];
+        acc[c][0] = mma_vec<T>(af, b[0], acc[c][0]);
+        acc[c][1] = mma_vec<T>(af, b[1], acc[c][1]);
+      }
+    };
+    if constexpr (NKS > 0) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) kstep(ks);
+    } else {
+      for (int ks = 0; ks < nks; ++ks) kstep(ks);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      if (ph0[pt] < (1 << 28)) {
+#pragma unroll
+        for (int c = 0; c < CT16; ++c) {
+          const int co = 16 * c + 4 * gq;
+          if (co < a.Cout) {
+            float v[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              v[jj] = acc[c][pt][jj];
+              st1[c][jj] += v[jj];
+              st2[c][jj] += v[jj] * v[jj];
+            }
+            store4v<TO>(Y + (unsigned)(yoff[pt] + co), v, a.accumulate != 0);
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int c = 0; c < CT16; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          st1[c][j] += __shfl_xor(st1[c][j], o, 64);
+          st2[c][j] += __shfl_xor(st2[c][j], o, 64);
+        }
+      }
+    __syncthreads();
+    if (r == 0) {
+#pragma unroll
+      for (int c = 0; c < CT16; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sStat[wv * 2 * CT + 16 * c + 4 * gq + j] = st1[c][j];
+          sStat[wv * 2 * CT + CT + 16 * c + 4 * gq + j] = st2[c][j];
+        }
+    }
+    __syncthreads();
+    if (t < 2 * CT) {
+      const float s = sStat[t] + sStat[2 * CT + t] + sStat[4 * CT + t] + sStat[6 * CT + t];
+      const int which = t / CT, cl = t - which * CT;
+      if (cl < a.Cout) a.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * a.Cout + (long)which * a.Cout + cl] = s;
+    }
+  }
+}
+
+size_t gather3_lds_bytes(const GatherArgs& a, int dt, int CT) {
+  int worst = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    const int kvecs = a.phases[p].ntaps * a.cin_vecs, kvp = (kvecs + 3) & ~3;
+    if (kvp > worst) worst = kvp;
+  }
+  return (size_t)CT * (worst + 1) * 16 + (size_t)worst * 16 + 1024 * 4 + (size_t)8 * CT * 4;
+}
+
+template <typename T, typename TO, int CT16>
+static void launch_gather3_nks(const GatherArgs& a, dim3 grid, size_t lds, int nks, hipStream_t s) {
+  dim3 block(256);
+  switch (nks) {
+    case 1: hipLaunchKernelGGL((gather3_kernel<T, TO, CT16, 1>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((gather3_kernel<T, TO, CT16, 2>), grid, block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL((gather3_kernel<T, TO, CT16, 4>), grid, block, lds, s, a); break;
+    case 8: hipLaunchKernelGGL((gather3_kernel<T, TO, CT16, 8>), grid, block, lds, s, a); break;
+    case 9: hipLaunchKernelGGL((gather3_kernel<T, TO, CT16, 9>), grid, block, lds, s, a); break;
+    default: hipLaunchKernelGGL((gather3_kernel<T, TO, CT16, 0>), grid, block, lds, s, a); break;
+  }
+}
+
+template <typename T, typename TO>
+static int launch_gather3_t(const GatherArgs& a, int dt, int gx, hipStream_t s) {
+  int ct16 = (a.Cout + 15) / 16;
+  if (ct16 == 3) ct16 = 4;
+  const size_t lds = gather3_lds_bytes(a, dt, ct16 * 16);
+  dim3 grid(gx, 1, a.nphase);
+  // all phases of a launch must share the unrolled step count, else the runtime-loop instance is used
+  int nks = -1;
+  for (int p = 0; p < a.nphase; ++p) {
+    const int k = (((a.phases[p].ntaps * a.cin_vecs) + 3) & ~3) >> 2;
+    nks = (nks < 0 || nks == k) ? k : 0;
+  }
+  switch (ct16) {
+    case 1: launch_gather3_nks<T, TO, 1>(a, grid, lds, nks, s); break;
+    case 2: launch_gather3_nks<T, TO, 2>(a, grid, lds, nks, s); break;
+    case 4: launch_gather3_nks<T, TO, 4>(a, grid, lds, nks, s); break;
+    default: set_error("gather3: Cout=%d too large", a.Cout); return MMVAE_ERR_UNSUPPORTED;
+  }
+  int rc = check_launch("gather3");
+  return rc ? rc : gx * a.nphase;
+}
+
+int launch_gather3(int dt, int out_dt, const GatherArgs& a, int gx, hipStream_t s) {
+  if (dt == DT_F32) return launch_gather3_t<float, float>(a, dt, gx, s);
+  if (out_dt != dt) { set_error("gather3: mixed output type unsupported"); return MMVAE_ERR_UNSUPPORTED; }
+  return launch_gather3_t<bf16_t, bf16_t>(a, dt, gx, s);
+}
+
+}  // namespace mmvae

@@ -29,6 +29,7 @@ struct GatherArgs {
   int cin_vecs;
   // optional boundary layouts (patch-tile kernels only):
   int x_planar, x_planes;  // 1: x is planar f32 [N][x_planes][Hi][Wi], 2: planar T; staged as Cin=16 channels, zero padded
+  int dbg;                 // developer switches (MMVAE_DBG): bit0 skip global loads, bit1 skip stores, bit2 skip MFMA
   int y_planes;            // >0: y is NCHW f32 [N][y_planes][Ho][Wo] (Cout = 16 padded GEMM rows; stats rows have y_planes channels)
 };
 // out_dt: dtype of y (may be DT_F32 while x/w are bf16).  Returns the number of stats partial rows (>0) or an error (<0).
@@ -86,6 +87,8 @@ struct Wgrad2Args {
 size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB);
 int wgrad2_taps_per_block(int ta16, int tb16, int ntaps);
 int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s);
+size_t gather3_lds_bytes(const GatherArgs& a, int dt, int CT);
+int launch_gather3(int dt, int out_dt, const GatherArgs& a, int gx, hipStream_t s);
 bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
 // ---------------------------------------------------------------- weight packing

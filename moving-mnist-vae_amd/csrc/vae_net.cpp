@@ -1,6 +1,7 @@
 #include "vae_net.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "conv_ops.hpp"
@@ -204,7 +205,15 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   float* stats = training ? part : nullptr;
   const int S = cfg.S;
   MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
-  {
+  static const bool stem_direct = [] { const char* e = getenv("MMVAE_STEM_DIRECT"); return e && e[0] == '1'; }();
+  if (stem_direct) {
+    MM_TRY(launch_stem_fwd(dt(), base + P.x_t, params + stem.off, base + P.y0, N, S, S, H1, W1, 32, s));
+    if (training) {
+      const int np = launch_chan_stats_nhwc(dt(), base + P.y0, (long)N * H1 * W1, 32, part, s);
+      MM_TRY(np);
+      MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
+    }
+  } else {
     // stem Conv2d(1 -> 32, k5 s2 p2) (model.py:94): the 1-channel image is staged as a zero-padded VE-channel NHWC patch
     // in LDS and runs through the MFMA patch-tile kernel; BatchNorm statistics come out of its epilogue.
     const int cpad = dt() == DT_F32 ? 4 : 8;
@@ -391,7 +400,15 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   }
   // tail conv (+bias) and the output BatchNorm (model.py:193)
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
-  {
+  static const bool tail_direct_f = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
+  if (tail_direct_f) {
+    MM_TRY(launch_tail_fwd(dt(), xin, params + tail.off, params + tail_bias, r_raw, N, Sd, Sd, cfg.out_ch, s));
+    if (training) {
+      np = launch_chan_stats_nchw(r_raw, N, cfg.out_ch, Sd * Sd, part, s);
+      MM_TRY(np);
+      MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
+    }
+  } else {
     // Conv2d(16 -> out_ch, k3 p1, bias): GEMM rows padded to 16 in LDS, epilogue stores the out_ch real rows as NCHW f32
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_f * (long)esz();
@@ -434,7 +451,10 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, grads + tail_bias, N, Sd, Sd, cfg.out_ch, s));
   }
   int cur = 0;
-  {
+  static const bool tail_direct = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
+  if (tail_direct) {
+    MM_TRY(launch_tail_dgrad(dt(), d_raw, params + tail.off, base + P.g[cur], N, Sd, Sd, cfg.out_ch, s));
+  } else {
     // dx[n,h,w,ci] = sum dy[n,oc,h+1-kh,w+1-kw] * w[oc][ci][kh][kw]: planar f32 source padded to 8 channels in LDS
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_d * (long)esz();
