@@ -306,7 +306,9 @@ static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   // largest tile (4, 2 or 1 sub-tiles of 128 pixels per barrier pair) that fits LDS and still leaves >= 1024 tiles
   size_t lds = 0;
   bool ok = false;
-  for (int sub = 1; sub >= 1 && !ok; sub >>= 1) {      // (multi-sub-tile tiles measured slower: occupancy beats tile size here)
+  // multi-sub-tile tiles pay off only for the wide, shallow boundary layers (tail conv: 64-wide rows, tiny patches);
+  // elsewhere occupancy beats tile size (measured)
+  for (int sub = boundary ? 4 : 1; sub >= 1 && !ok; sub >>= 1) {
     bool geo = true;
     max_tiles = 0;
     for (int p = 0; p < a.nphase && geo; ++p) {
@@ -561,15 +563,33 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
   const int zg = (a.ntaps + b.TG - 1) / b.TG;
   int gx = 1024 / (tiles_ab * zg); if (gx < 1) gx = 1;
-  {                                                     // each persistent block flushes its whole dW tile once:
-    const long wsize = (long)a.Ca * a.Cb * a.ntaps;     // keep the global float atomics of a launch below ~3M
+  const long wsize = (long)a.Ca * a.Cb * a.ntaps;
+  const bool via_scratch = a.scratch != nullptr && wsize >= 32768;
+  if (via_scratch) {
+    // Large gradients: every persistent block flushes its dW tile with float atomics.  Straight into the PyTorch layout
+    // those are scattered (stride k*k) and slow, which used to cap the grid at ~1 block per CU.  Reduce into a
+    // [tap][a][b] scratch image instead (256-byte contiguous atomic rows run at the full atomic rate), then un-permute.
+    hipError_t e = hipMemsetAsync(a.scratch, 0, (size_t)wsize * sizeof(float), s);
+    if (e != hipSuccess) { set_error("wgrad: memset scratch: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
+    b.dW = a.scratch; b.sA = a.Cb; b.sB = 1; b.scale = 1.f; b.flush_per_tap = 1;
+    for (int t = 0; t < a.ntaps; ++t) b.tap_off[t] = t * a.Ca * a.Cb;
+  } else {                                              // direct flush: keep the scattered atomics of a launch below ~3M
     long cap = (3L << 20) / (wsize > 0 ? wsize : 1);
     if (cap < 2) cap = 2;
     if (gx > cap) gx = (int)cap;
   }
   if (gx > b.g.ntiles) gx = b.g.ntiles;
   const int rc = launch_wgrad2(dt, b, gx, tiles_ab, zg, ta16, tb16, s);
-  return rc < 0 ? rc : 1;
+  if (rc < 0) return rc;
+  if (via_scratch) {
+    UnpermuteArgs u; memset(&u, 0, sizeof(u));
+    u.scratch = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid;
+    u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
+    for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
+    const int rc2 = launch_wgrad_unpermute(u, s);
+    if (rc2 < 0) return rc2;
+  }
+  return 1;
 }
 
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {

@@ -19,6 +19,7 @@ int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N
 int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
               const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s);
 int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
-                 const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s);
+                 const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s,
+                 float* scratch = nullptr);
 
 }  // namespace mmvae

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
   __syncthreads();
   float* sAcc = reinterpret_cast<float*>(smem);
   const int nacc = TA * TB * tg_n;
-  if ((size_t)nacc * 4 <= (size_t)a.lds_bytes) {
+  if (!a.flush_per_tap && (size_t)nacc * 4 <= (size_t)a.lds_bytes) {
     for (int i = t; i < nacc; i += 256) sAcc[i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -605,6 +605,22 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
       }
     }
   }
+}
+
+__global__ void wgrad_unpermute_kernel(UnpermuteArgs a) {
+  const long total = (long)a.ntaps * a.Ca * a.Cb;
+  const int ab = a.Ca * a.Cb;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i / ab), rem = (int)(i - (long)t * ab);
+    const int aa = rem / a.Cb, bb = rem - aa * a.Cb;
+    if (aa < a.Ca_valid && bb < a.Cb_valid) a.dW[(long)aa * a.sA + (long)bb * a.sB + a.tap_off[t]] += a.scratch[i] * a.scale;
+  }
+}
+int launch_wgrad_unpermute(const UnpermuteArgs& a, hipStream_t s) {
+  const long total = (long)a.ntaps * a.Ca * a.Cb;
+  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_unpermute_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return check_launch("wgrad_unpermute");
 }
 
 int wgrad2_taps_per_block(int ta16, int tb16, int ntaps) {

@@ -30,6 +30,7 @@ ConvW Net::add_conv(const std::string& name, int D0, int D1, int k, int s, int p
   add_entry(name, {D0, D1, k, k}, EK_PARAM, n_params);
   const long numel = (long)D0 * D1 * k * k;
   n_params += numel;
+  if (numel > max_w) max_w = numel;
   if (pack) { w.packD = n_packed; n_packed += align_up(numel, 8); w.packU = n_packed; n_packed += align_up(numel, 8); }
   return w;
 }
@@ -134,6 +135,7 @@ const Plan& Net::plan(int N) {
   for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
   P.dy1 = take(maxact); P.dy2 = take(maxact); P.dys = take(maxact); P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
+  P.wscratch = take(std::max(max_w, 4L * cfg.z * 256) * 4);
   P.bytes = (size_t)cur;
   plan_ = P;
   return plan_;
@@ -164,7 +166,7 @@ int Net::run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws
 }
 int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
                    const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s) {
-  return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s);
+  return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_);
 }
 
 int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s) {
@@ -283,6 +285,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
   const Plan& P = plan(N);
   if (ws_bytes < P.bytes) { set_error("workspace too small"); return MMVAE_ERR_WORKSPACE; }
   char* base = static_cast<char*>(ws);
+  wscratch_ = reinterpret_cast<float*>(base + P.wscratch);
   float* part = reinterpret_cast<float*>(base + P.partials);
   const int Ch = cfg.need_logvar ? 2 * cfg.z : cfg.z;
   const int nt = Hf * Wf;
@@ -293,6 +296,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     a.P = base + P.dh; a.G = base + enc[3].out; a.dW = grads + head_mu.off; a.proP_relu = a.proG_relu = 0;
     a.N = N; a.Hp = 1; a.Wp = 1; a.Ca = Ch; a.Hg = Hf; a.Wg = Wf; a.Cb = 256; a.Cb_valid = 256;
     a.stride = Hf; a.pad = 0; a.ksz = Hf; a.sA = 256; a.sB = 1; a.ntaps = nt; a.scale = 1.0f / nt;
+    a.scratch = wscratch_;
     MM_TRY(launch_wgrad(dt(), a, s));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
@@ -437,6 +441,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   const Plan& P = plan(N);
   if (ws_bytes < P.bytes) { set_error("workspace too small"); return MMVAE_ERR_WORKSPACE; }
   char* base = static_cast<char*>(ws);
+  wscratch_ = reinterpret_cast<float*>(base + P.wscratch);
   float* part = reinterpret_cast<float*>(base + P.partials);
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
   float* d_raw = reinterpret_cast<float*>(base + P.d_raw);

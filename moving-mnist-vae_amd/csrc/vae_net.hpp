@@ -35,6 +35,7 @@ struct Plan {
   long bnws;                                             // float scratch for all BNs
   long partials;                                         // reduction partials (floats)
   long g[2], dy1, dy2, dys, da1, dh;                     // backward temporaries
+  long wscratch;                                         // [tap][a][b] reduction image of the largest weight gradient
   long enc_ws_end;
 };
 
@@ -47,6 +48,7 @@ class Net {
   long dec_param_off = 0;            // first decoder parameter (flat f32 index)
   long n_packed = 0;                 // packed weight elements
   long n_bnws = 0;                   // floats of BN scratch
+  long max_w = 0;                    // elements of the largest conv weight
   int H1, W1, Hf, Wf, Sd, nup;
   // layers
   ConvW stem; Bn bn0;
@@ -71,6 +73,7 @@ class Net {
 
  private:
   Plan plan_;
+  float* wscratch_ = nullptr;
   int dt() const { return cfg.dtype; }
   size_t esz() const { return dtype_size(cfg.dtype); }
   ConvW add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack);
