@@ -653,9 +653,59 @@ __global__ void pack_kernel(PackArgs a) {
   }
 }
 
+struct PackJob {
+  const float* src; void* dst; int cols, K, ntaps, s_col, s_k, cols_valid, K_valid; float scale; unsigned char tap_off[28];
+};
+constexpr int kPackJobsPerLaunch = 48;
+struct PackMulti { int njobs; int pad; PackJob jobs[kPackJobsPerLaunch]; };
+
+template <typename T>
+__global__ void pack_multi_kernel(PackMulti m) {
+  const PackJob& a = m.jobs[blockIdx.y];
+  const long total = (long)a.cols * a.ntaps * a.K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % a.K);
+    const long q = i / a.K;
+    const int tp = (int)(q % a.ntaps);
+    const int col = (int)(q / a.ntaps);
+    const bool real = (a.cols_valid <= 0 || col < a.cols_valid) && (a.K_valid <= 0 || k < a.K_valid);
+    const float v = real ? a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale : 0.f;
+    Elem<T>::store(reinterpret_cast<T*>(a.dst) + i, v);
+  }
+}
+
+static thread_local bool g_pack_batching = false;
+static thread_local int g_pack_n = 0;
+static thread_local PackJob g_pack_jobs[256];
+
+void pack_batch_begin() { g_pack_batching = true; g_pack_n = 0; }
+
+int pack_batch_flush(int dt, hipStream_t s) {
+  g_pack_batching = false;
+  for (int j0 = 0; j0 < g_pack_n; j0 += kPackJobsPerLaunch) {
+    PackMulti m; m.njobs = g_pack_n - j0 < kPackJobsPerLaunch ? g_pack_n - j0 : kPackJobsPerLaunch; m.pad = 0;
+    for (int j = 0; j < m.njobs; ++j) m.jobs[j] = g_pack_jobs[j0 + j];
+    dim3 grid(32, m.njobs), block(256);
+    if (dt == DT_F32) hipLaunchKernelGGL((pack_multi_kernel<float>), grid, block, 0, s, m);
+    else hipLaunchKernelGGL((pack_multi_kernel<bf16_t>), grid, block, 0, s, m);
+    int rc = check_launch("pack_multi");
+    if (rc) { g_pack_n = 0; return rc; }
+  }
+  g_pack_n = 0;
+  return MMVAE_OK;
+}
+
 int launch_pack(int dt, const PackArgs& a, hipStream_t s) {
   const long total = (long)a.cols * a.ntaps * a.K;
   if (total <= 0) return MMVAE_OK;
+  if (g_pack_batching) {
+    if (g_pack_n >= 256 || a.ntaps > 28) { set_error("pack batch overflow"); return MMVAE_ERR_ARG; }
+    PackJob& j = g_pack_jobs[g_pack_n++];
+    j.src = a.src; j.dst = a.dst; j.cols = a.cols; j.K = a.K; j.ntaps = a.ntaps; j.s_col = a.s_col; j.s_k = a.s_k;
+    j.cols_valid = a.cols_valid; j.K_valid = a.K_valid; j.scale = a.scale;
+    for (int t = 0; t < a.ntaps; ++t) j.tap_off[t] = (unsigned char)a.tap_off[t];
+    return MMVAE_OK;
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (dt == DT_F32) hipLaunchKernelGGL((pack_kernel<float>), dim3(blocks), dim3(256), 0, s, a);

@@ -103,6 +103,10 @@ struct PackArgs {
   int cols_valid, K_valid;   // >0: columns / k beyond these are written as zero (channel padding), source not read
 };
 int launch_pack(int dt, const PackArgs& a, hipStream_t s);
+// Batched packing: between pack_batch_begin() and pack_batch_flush() every launch_pack() call is only recorded;
+// flush packs all recorded jobs with ONE kernel (grid.y = job).  Not re-entrant (one host thread per net).
+void pack_batch_begin();
+int pack_batch_flush(int dt, hipStream_t s);
 
 // ---------------------------------------------------------------- direct stem / tail kernels
 // stem: Conv2d(1 -> Cout<=32 multiple of 8, k5 s2 p2), x [N,H,W] (T) -> y [N,Ho,Wo,Cout] (T)

@@ -195,6 +195,82 @@ int Net::bn_backward_coefs(const Bn& bn, const float* params, float* grads, char
   return launch_bn_bwd_finalize(a, s);
 }
 
+// ------------------------------------------------------------------------------------------------ weight re-packs per entry point
+// (recorded by launch_pack() while a batch is open; see pack_batch_begin/flush)
+int Net::packs_enc_fwd(const float* params, char* base, hipStream_t s) {
+  const Plan& P = plan_;
+  {
+    const int cpad = dt() == DT_F32 ? 4 : 8;
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = params + stem.off; pa.dst = base + P.packed + stem_pack * (long)esz();
+    pa.cols = 32; pa.K = cpad; pa.K_valid = 1; pa.ntaps = 25; pa.s_col = 25; pa.s_k = 25; pa.scale = 1.f;
+    for (int t = 0; t < 25; ++t) pa.tap_off[t] = t;
+    MM_TRY(launch_pack(dt(), pa, s));
+  }
+  for (int i = 0; i < 4; ++i) {
+    MM_TRY(pack_down(enc[i].c1, params, base, s));
+    MM_TRY(pack_down(enc[i].c2, params, base, s));
+    MM_TRY(pack_down(enc[i].cs, params, base, s));
+  }
+  const int nt = Hf * Wf;
+  for (int h = 0; h < (cfg.need_logvar ? 2 : 1); ++h) {
+    const ConvW& hw = h == 0 ? head_mu : head_lv;
+    const long poff = h == 0 ? head_pack_mu : head_pack_lv;
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = params + hw.off; pa.dst = base + P.packed + poff * (long)esz();
+    pa.cols = cfg.z; pa.K = 256; pa.ntaps = nt; pa.s_col = 256; pa.s_k = 1; pa.scale = 1.0f / nt;
+    MM_TRY(launch_pack(dt(), pa, s));
+  }
+  return MMVAE_OK;
+}
+
+int Net::packs_enc_bwd(const float* params, char* base, hipStream_t s) {
+  const Plan& P = plan_;
+  const int Ch = cfg.need_logvar ? 2 * cfg.z : cfg.z;
+  PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+  pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
+  pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / (Hf * Wf);
+  MM_TRY(launch_pack(dt(), pa, s));
+  for (int i = 0; i < 4; ++i) {
+    MM_TRY(pack_up(enc[i].c2, params, base, s));
+    MM_TRY(pack_up(enc[i].c1, params, base, s));
+    MM_TRY(pack_up(enc[i].cs, params, base, s));
+  }
+  return MMVAE_OK;
+}
+
+int Net::packs_dec_fwd(const float* params, char* base, hipStream_t s) {
+  const Plan& P = plan_;
+  MM_TRY(pack_up(dstem, params, base, s));
+  for (int i = 0; i < nup; ++i) {
+    MM_TRY(pack_down(dec[i].c1, params, base, s));
+    MM_TRY(pack_up(dec[i].c2, params, base, s));
+    MM_TRY(pack_up(dec[i].cs, params, base, s));
+  }
+  PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+  pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_f * (long)esz();
+  pa.cols = 16; pa.cols_valid = cfg.out_ch; pa.K = 16; pa.ntaps = 9; pa.s_col = 144; pa.s_k = 9; pa.scale = 1.f;
+  for (int t = 0; t < 9; ++t) pa.tap_off[t] = t;
+  MM_TRY(launch_pack(dt(), pa, s));
+  return MMVAE_OK;
+}
+
+int Net::packs_dec_bwd(const float* params, char* base, bool need_denc, hipStream_t s) {
+  const Plan& P = plan_;
+  PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+  pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_d * (long)esz();
+  pa.cols = 16; pa.K = 8; pa.K_valid = cfg.out_ch; pa.ntaps = 9; pa.s_col = 9; pa.s_k = 144; pa.scale = 1.f;
+  for (int t = 0; t < 9; ++t) pa.tap_off[t] = t;
+  MM_TRY(launch_pack(dt(), pa, s));
+  for (int i = 0; i < nup; ++i) {
+    MM_TRY(pack_down(dec[i].c2, params, base, s));
+    MM_TRY(pack_up(dec[i].c1, params, base, s));
+    MM_TRY(pack_down(dec[i].cs, params, base, s));
+  }
+  if (need_denc) MM_TRY(pack_down(dstem, params, base, s));
+  return MMVAE_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ encoder
 int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
                      float* mu, float* logvar, int training, hipStream_t s) {
@@ -206,6 +282,9 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   float* part = reinterpret_cast<float*>(base + P.partials);
   float* stats = training ? part : nullptr;
   const int S = cfg.S;
+  pack_batch_begin();                       // every weight re-pack of this entry point in ONE launch
+  MM_TRY(packs_enc_fwd(params, base, s));
+  MM_TRY(pack_batch_flush(dt(), s));
   MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
   static const bool stem_direct = [] { const char* e = getenv("MMVAE_STEM_DIRECT"); return e && e[0] == '1'; }();
   if (stem_direct) {
@@ -223,7 +302,6 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
     pa.src = params + stem.off; pa.dst = base + P.packed + stem_pack * (long)esz();
     pa.cols = 32; pa.K = cpad; pa.K_valid = 1; pa.ntaps = 25; pa.s_col = 25; pa.s_k = 25; pa.scale = 1.f;
     for (int t = 0; t < 25; ++t) pa.tap_off[t] = t;
-    MM_TRY(launch_pack(dt(), pa, s));
     GatherArgs a; std::memset(&a, 0, sizeof(a));
     a.x = base + P.x_t; a.w = pa.dst; a.y = base + P.y0; a.stats = stats;
     a.x_planar = 2; a.x_planes = 1;
@@ -244,9 +322,6 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   for (int i = 0; i < 4; ++i) {
     Block& B = enc[i];
     const double cnt = (double)N * B.Hout * B.Wout;
-    MM_TRY(pack_down(B.c1, params, base, s));
-    MM_TRY(pack_down(B.c2, params, base, s));
-    MM_TRY(pack_down(B.cs, params, base, s));
     int np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b1, params, bnbuf, base, s));
@@ -269,7 +344,6 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + hw.off; pa.dst = base + P.packed + poff * (long)esz();
     pa.cols = cfg.z; pa.K = 256; pa.ntaps = nt; pa.s_col = 256; pa.s_k = 1; pa.scale = 1.0f / nt;
-    MM_TRY(launch_pack(dt(), pa, s));
     GatherArgs a; std::memset(&a, 0, sizeof(a));
     a.x = xin; a.w = base + P.packed + poff * (long)esz(); a.y = h == 0 ? mu : logvar;
     a.N = N; a.Hi = Hf; a.Wi = Wf; a.Cin = 256; a.Ho = 1; a.Wo = 1; a.Cout = cfg.z; a.SI = Hf; a.SO = 1;
@@ -289,6 +363,9 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
   float* part = reinterpret_cast<float*>(base + P.partials);
   const int Ch = cfg.need_logvar ? 2 * cfg.z : cfg.z;
   const int nt = Hf * Wf;
+  pack_batch_begin();
+  MM_TRY(packs_enc_bwd(params, base, s));
+  MM_TRY(pack_batch_flush(dt(), s));
   // ---- heads: dh = [d_mu | d_logvar] in T
   MM_TRY(launch_concat2_to_t(dt(), d_mu, cfg.need_logvar ? d_logvar : nullptr, N, cfg.z, cfg.need_logvar ? cfg.z : 0, base + P.dh, s));
   {
@@ -301,7 +378,6 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
     pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / nt;
-    MM_TRY(launch_pack(dt(), pa, s));
     GatherArgs g; std::memset(&g, 0, sizeof(g));
     g.x = base + P.dh; g.w = pa.dst; g.y = base + P.g[0];
     g.N = N; g.Hi = 1; g.Wi = 1; g.Cin = Ch; g.Ho = Hf; g.Wo = Wf; g.Cout = 256; g.SI = 1; g.SO = Hf;
@@ -328,7 +404,6 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
     MM_TRY(run_wgrad(B.c2, N, base + P.dy2, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
                      bnf(B.b1, base, 3), grads, s));
-    MM_TRY(pack_up(B.c2, params, base, s));
     MM_TRY(run_up(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
     // bn1 + relu backward
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
@@ -340,8 +415,6 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // conv1 (3x3 s2) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
     MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
     MM_TRY(run_wgrad(B.cs, N, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
-    MM_TRY(pack_up(B.c1, params, base, s));
-    MM_TRY(pack_up(B.cs, params, base, s));
     MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
     MM_TRY(run_up(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     cur ^= 1;
@@ -374,9 +447,11 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   char* base = static_cast<char*>(ws);
   float* part = reinterpret_cast<float*>(base + P.partials);
   float* stats = training ? part : nullptr;
+  pack_batch_begin();
+  MM_TRY(packs_dec_fwd(params, base, s));
+  MM_TRY(pack_batch_flush(dt(), s));
   MM_TRY(launch_convert(DT_F32, dt(), encv, base + P.enc_t, (long)N * cfg.z, s));
   // stem ConvTranspose2d(z -> 128, k2) on the 1x1 latent (model.py:159-161,182)
-  MM_TRY(pack_up(dstem, params, base, s));
   int np = run_up(dstem, base, N, base + P.enc_t, 1, 1, base + P.y0d, 2, 2, nullptr, nullptr, 0, stats, 0, s);
   MM_TRY(np);
   MM_TRY(training ? bn_train(dbn0, params, bnbuf, nbt, base, np, (double)N * 4, s) : bn_eval(dbn0, params, bnbuf, base, s));
@@ -385,9 +460,6 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   const float* xb = bnf(dbn0, base, 3);
   for (int i = 0; i < nup; ++i) {
     Block& B = dec[i];
-    MM_TRY(pack_down(B.c1, params, base, s));
-    MM_TRY(pack_up(B.c2, params, base, s));
-    MM_TRY(pack_up(B.cs, params, base, s));
     np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hin, B.Win, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, (double)N * B.Hin * B.Win, s) : bn_eval(B.b1, params, bnbuf, base, s));
@@ -418,7 +490,6 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_f * (long)esz();
     pa.cols = 16; pa.cols_valid = cfg.out_ch; pa.K = 16; pa.ntaps = 9; pa.s_col = 144; pa.s_k = 9; pa.scale = 1.f;
     for (int t = 0; t < 9; ++t) pa.tap_off[t] = t;
-    MM_TRY(launch_pack(dt(), pa, s));
     GatherArgs a; std::memset(&a, 0, sizeof(a));
     a.x = xin; a.w = pa.dst; a.y = r_raw; a.bias = params + tail_bias; a.stats = stats; a.y_planes = cfg.out_ch;
     a.N = N; a.Hi = Sd; a.Wi = Sd; a.Cin = 16; a.Ho = Sd; a.Wo = Sd; a.Cout = 16; a.SI = 1; a.SO = 1;
@@ -446,6 +517,9 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
   float* d_raw = reinterpret_cast<float*>(base + P.d_raw);
   const int HW = Sd * Sd;
+  pack_batch_begin();
+  MM_TRY(packs_dec_bwd(params, base, d_enc != nullptr, s));
+  MM_TRY(pack_batch_flush(dt(), s));
   // ---- output BN backward, tail conv backward
   int np = launch_bn_bwd_reduce_nchw(d_recon, r_raw, N, cfg.out_ch, HW, part, s);
   MM_TRY(np);
@@ -465,7 +539,6 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_d * (long)esz();
     pa.cols = 16; pa.K = 8; pa.K_valid = cfg.out_ch; pa.ntaps = 9; pa.s_col = 9; pa.s_k = 144; pa.scale = 1.f;
     for (int t = 0; t < 9; ++t) pa.tap_off[t] = t;
-    MM_TRY(launch_pack(dt(), pa, s));
     GatherArgs a; std::memset(&a, 0, sizeof(a));
     a.x = d_raw; a.w = pa.dst; a.y = base + P.g[cur]; a.x_planar = 1; a.x_planes = cfg.out_ch;
     a.N = N; a.Hi = Sd; a.Wi = Sd; a.Cin = 8; a.Ho = Sd; a.Wo = Sd; a.Cout = 16; a.SI = 1; a.SO = 1;
@@ -489,7 +562,6 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
     MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2, B.Hout, B.Wout, nullptr,
                      nullptr, grads, s));
-    MM_TRY(pack_down(B.c2, params, base, s));
     MM_TRY(run_down(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
     MM_TRY(np);
@@ -501,8 +573,6 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
     MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, grads, s));
     // d_xin = dgrad(conv1)(dy1) + dgrad(upsample)(dys)
-    MM_TRY(pack_up(B.c1, params, base, s));
-    MM_TRY(pack_down(B.cs, params, base, s));
     MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
     MM_TRY(run_down(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, dt(), s));
     cur ^= 1;
@@ -517,7 +587,6 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                bnf(dbn0, base, 5), bnf(dbn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 128, s));
     MM_TRY(run_wgrad(dstem, N, base + P.enc_t, 1, 1, nullptr, nullptr, base + P.dy1, 2, 2, nullptr, nullptr, grads, s));
     if (d_enc) {
-      MM_TRY(pack_down(dstem, params, base, s));
       MM_TRY(run_down(dstem, base, N, base + P.dy1, 2, 2, base + P.dh, 1, 1, nullptr, nullptr, 0, nullptr, 0, dt(), s));
       MM_TRY(launch_convert(dt(), DT_F32, base + P.dh, d_enc, (long)N * cfg.z, s));
     }

@@ -80,6 +80,10 @@ class Net {
   Bn add_bn(const std::string& prefix, int C);
   void add_entry(const std::string& name, std::initializer_list<int> shape, int kind, long off);
 
+  int packs_enc_fwd(const float* params, char* base, hipStream_t s);
+  int packs_enc_bwd(const float* params, char* base, hipStream_t s);
+  int packs_dec_fwd(const float* params, char* base, hipStream_t s);
+  int packs_dec_bwd(const float* params, char* base, bool need_denc, hipStream_t s);
   int pack_down(const ConvW& w, const float* params, char* base, hipStream_t s);
   int pack_up(const ConvW& w, const float* params, char* base, hipStream_t s);
   int run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
