@@ -101,8 +101,9 @@ MMVAE_API int mmvae_ce_fwd(const float* recon, const int64_t* target, const floa
 MMVAE_API int mmvae_ce_bwd(const float* recon, const int64_t* target, const float* weight, int N, int Q, int HW, float coef,
                  const float* gscale, float* d_recon, void* stream);
 /* acc[0] += sum k(x,x) + sum k(y,y) - 2 sum k(x,y),  k(a,b) = exp(-|a-b|^2 / d^2)   (compute_mmd, model.py:367-383);
- * x = true_samples, y = encoding, both [n,d] f32.  Never materialises (n,n,d). */
-MMVAE_API int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, double* acc, void* stream);
+ * x = true_samples, y = encoding, both [n,d] f32.  Never materialises (n,n,d).  scratch: 2n floats (row norms) selects the
+ * exact-f32 MFMA path |x|^2+|y|^2-2x.y; NULL the direct (x-y)^2 VALU path. */
+MMVAE_API int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, float* scratch, double* acc, void* stream);
 /* d_y += coef * d(mmd)/dy */
 MMVAE_API int mmvae_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, void* stream);
 /* acc = {px, kl, mmd} (f64) -> out[4] = {(nll*px + kl_coef*kl + mmd_coef*mmd)/n, nll*px/n, kl/n, mmd/n}  (model.py:405-406) */

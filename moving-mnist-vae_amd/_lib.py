@@ -36,7 +36,7 @@ PROTOTYPES = {
     "mmvae_gauss_nll_bwd": (c_int, [P, P, c_int64, c_float, c_float, P, P, P]),
     "mmvae_ce_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "mmvae_ce_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, P]),
-    "mmvae_mmd_fwd": (c_int, [P, P, c_int, c_int, P, P]),
+    "mmvae_mmd_fwd": (c_int, [P, P, c_int, c_int, P, P, P]),
     "mmvae_mmd_bwd": (c_int, [P, P, c_int, c_int, c_float, P, P, P]),
     "mmvae_loss_finish": (c_int, [P, P, c_float, c_float, c_float, c_float, P]),
     "mmvae_normalise_labels": (c_int, [P, c_int64, c_float, c_float, P, P]),

@@ -108,7 +108,9 @@ int mmvae_ce_bwd(const float* r, const int64_t* t, const float* w, int N, int Q,
                  void* st) {
   return launch_ce_bwd(r, reinterpret_cast<const long long*>(t), w, N, Q, HW, coef, gscale, d_r, S(st));
 }
-int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, double* acc, void* st) { return launch_mmd_fwd(x, y, n, d, acc, S(st)); }
+int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, float* scratch, double* acc, void* st) {
+  return scratch ? launch_mmd_fwd_mfma(x, y, n, d, scratch, acc, S(st)) : launch_mmd_fwd(x, y, n, d, acc, S(st));
+}
 int mmvae_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, void* st) {
   return launch_mmd_bwd(x, y, n, d, coef, gscale, d_y, S(st));
 }

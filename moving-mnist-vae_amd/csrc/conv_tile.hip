@@ -613,7 +613,8 @@ __global__ void wgrad_unpermute_kernel(UnpermuteArgs a) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i / ab), rem = (int)(i - (long)t * ab);
     const int aa = rem / a.Cb, bb = rem - aa * a.Cb;
-    if (aa < a.Ca_valid && bb < a.Cb_valid) a.dW[(long)aa * a.sA + (long)bb * a.sB + a.tap_off[t]] += a.scratch[i] * a.scale;
+    // atomic: several taps may alias one destination (the pooled 1x1 heads share one weight across taps)
+    if (aa < a.Ca_valid && bb < a.Cb_valid) atomicAdd(a.dW + (long)aa * a.sA + (long)bb * a.sB + a.tap_off[t], a.scratch[i] * a.scale);
   }
 }
 int launch_wgrad_unpermute(const UnpermuteArgs& a, hipStream_t s) {

@@ -183,6 +183,7 @@ int launch_ce_bwd(const float* r, const long long* t, const float* w, int N, int
                   hipStream_t s);
 // MMD (sums): out += sum_ij k(x_i,x_j) + sum_ij k(y_i,y_j) - 2 sum_ij k(x_i,y_j), k = exp(-|a-b|^2/d^2)
 int launch_mmd_fwd(const float* x, const float* y, int n, int d, double* out, hipStream_t s);
+int launch_mmd_fwd_mfma(const float* x, const float* y, int n, int d, float* scratch /*2n floats*/, double* out, hipStream_t s);
 // d_y[j] += coef * d(mmd)/d(y_j)
 int launch_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, hipStream_t s);
 

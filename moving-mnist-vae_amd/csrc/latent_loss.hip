@@ -202,11 +202,93 @@ __global__ __launch_bounds__(256) void mmd_fwd_kernel(const float* __restrict__ 
       if (i0 + ti + 16 * a < n && j0 + tj + 16 * b < n) sum += (double)expf(-acc[a][b] * inv);
   block_atomic_add_d(which == 2 ? -2.0 * sum : sum, out);
 }
+// MFMA version (exact f32, v_mfma_f32_16x16x4_f32): a 64x64 tile of pairs per block, each wave a 32x32 quadrant as 2x2
+// MFMA tiles; S = A B^T accumulated over d in LDS chunks of 32, then k = exp(-(|a|^2 + |b|^2 - 2S)/d^2).
+// The symmetric xx / yy sums visit only tiles with j-tile >= i-tile (off-diagonal tiles count twice).
+__global__ void row_sqnorm_kernel(const float* __restrict__ x, int n, int d, float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float a = 0.f;
+  for (int k = lane; k < d; k += 64) { const float v = x[(long)row * d + k]; a += v * v; }
+  a = wave_sum(a);
+  if (lane == 0) out[row] = a;
+}
+
+__global__ __launch_bounds__(256) void mmd_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ nx, const float* __restrict__ ny, int n, int d,
+                                                           double* out) {
+  __shared__ float sA[64][33];
+  __shared__ float sB[64][33];
+  const int which = blockIdx.z;     // 0: xx, 1: yy, 2: xy
+  const int it = blockIdx.y, jt = blockIdx.x;
+  if (which < 2 && jt < it) return;                 // symmetric: upper triangle of tiles only (uniform per block)
+  const float* A = which == 1 ? y : x;
+  const float* B = which == 0 ? x : y;
+  const float* nA = which == 1 ? ny : nx;
+  const float* nB = which == 0 ? nx : ny;
+  const int i0 = it * 64, j0 = jt * 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
+  const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;   // this wave's 32x32 quadrant
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
+  for (int k0 = 0; k0 < d; k0 += 32) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < 64 * 32; v += 256) {
+      const int rr = v >> 5, kk = v & 31;
+      sA[rr][kk] = (i0 + rr < n && k0 + kk < d) ? A[(long)(i0 + rr) * d + k0 + kk] : 0.f;
+      sB[rr][kk] = (j0 + rr < n && k0 + kk < d) ? B[(long)(j0 + rr) * d + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = sA[wi + 16 * a + r][4 * ks + g];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bv[b] = sB[wj + 16 * b + r][4 * ks + g];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  const float inv = 1.0f / ((float)d * (float)d);
+  double sum = 0.0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = j0 + wj + 16 * b + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + wi + 16 * a + 4 * g + q;      // D layout: row = 4*(lane>>4) + reg, col = lane&15
+        if (i < n && j < n) {
+          const float d2 = fmaxf(nA[i] + nB[j] - 2.0f * acc[a][b][q], 0.f);
+          sum += (double)expf(-d2 * inv);
+        }
+      }
+    }
+  if (which < 2 && jt > it) sum *= 2.0;
+  block_atomic_add_d(which == 2 ? -2.0 * sum : sum, out);
+}
+
 int launch_mmd_fwd(const float* x, const float* y, int n, int d, double* out, hipStream_t s) {
   if (n <= 0) return MMVAE_OK;
   const int tiles = (n + 63) / 64;
   hipLaunchKernelGGL(mmd_fwd_kernel, dim3(tiles, tiles, 3), dim3(256), 0, s, x, y, n, d, out);
   return check_launch("mmd_fwd");
+}
+// scratch: 2*n floats (row squared norms of x and y)
+int launch_mmd_fwd_mfma(const float* x, const float* y, int n, int d, float* scratch, double* out, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  const int tiles = (n + 63) / 64;
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, n, d, scratch);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, y, n, d, scratch + n);
+  hipLaunchKernelGGL(mmd_fwd_mfma_kernel, dim3(tiles, tiles, 3), dim3(256), 0, s, x, y, scratch, scratch + n, n, d, out);
+  return check_launch("mmd_fwd_mfma");
 }
 
 // d mmd / d y_j = -(4/d^2) sum_i k(y_i,y_j)(y_j - y_i) + (4/d^2) sum_i k(x_i,y_j)(y_j - x_i).  One block per j.

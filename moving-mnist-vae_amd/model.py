@@ -157,7 +157,8 @@ class _LossFn(torch.autograd.Function):
             check(L.mmvae_kl_fwd(ptr(mu), ptr(logvar), mu.numel(), base + 8, st), "mmvae_kl_fwd")
         if encoding is not None:
             encoding = encoding.contiguous()
-            check(L.mmvae_mmd_fwd(ptr(true_samples), ptr(encoding), N, encoding.shape[1], base + 16, st), "mmvae_mmd_fwd")
+            scratch = torch.empty(2 * N, dtype=torch.float32, device=dev)
+            check(L.mmvae_mmd_fwd(ptr(true_samples), ptr(encoding), N, encoding.shape[1], ptr(scratch), base + 16, st), "mmvae_mmd_fwd")
         if categorical:
             target = target.contiguous()
             Q, HW = recon.shape[1], recon.shape[2] * recon.shape[3]
@@ -449,7 +450,7 @@ class VAE(nn.Module):
     def compute_mmd(self, x, y):                               # model.py:378-383
         acc = torch.zeros(1, dtype=torch.float64, device=x.device)
         x, y = x.contiguous().float(), y.contiguous().float()
-        check(lib().mmvae_mmd_fwd(ptr(x), ptr(y), x.shape[0], x.shape[1], ptr(acc), _stream()), "mmvae_mmd_fwd")
+        check(lib().mmvae_mmd_fwd(ptr(x), ptr(y), x.shape[0], x.shape[1], None, ptr(acc), _stream()), "mmvae_mmd_fwd")
         return acc[0].float()
 
     def loss(self, target, encoding_mu, encoding_logvar, encoding, reconstruction, device, args):
