@@ -235,18 +235,23 @@ int launch_affine_act(int dt, const void* a, const float* sa, const float* ba, i
 }
 
 // ---------------------------------------------------------------- backward reductions
-// MODE 0: mask from out>0 ; MODE 1: mask from y0*ms+mb>0 ; MODE 2: no mask
+// MODE 0: mask from out>0 ; MODE 1: mask from y0*ms+mb>0 ; MODE 2: no mask ;
+// MODE 3: mask from (y0*ms+mb) + (y1*ms1+mb1) > 0  (the residual join recomputed -> `out` is not read at all)
 template <typename T, int NY, int MODE>
 __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out, const float* __restrict__ ms,
-                                     const float* __restrict__ mb, const T* __restrict__ y0, const T* __restrict__ y1,
+                                     const float* __restrict__ mb, const float* __restrict__ ms1, const float* __restrict__ mb1,
+                                     const T* __restrict__ y0, const T* __restrict__ y1,
                                      long nvec, int C, float* __restrict__ partials) {
   constexpr int VE = Elem<T>::kVec;
   extern __shared__ float smem[];
   const int cvecs = C / VE;
   const int cg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % cvecs);
-  float msc[VE], msh[VE];
+  float msc[VE], msh[VE], msc1[VE], msh1[VE];
 #pragma unroll
-  for (int j = 0; j < VE; ++j) { msc[j] = MODE == 1 ? ms[cg * VE + j] : 0.f; msh[j] = MODE == 1 ? mb[cg * VE + j] : 0.f; }
+  for (int j = 0; j < VE; ++j) {
+    msc[j] = (MODE == 1 || MODE == 3) ? ms[cg * VE + j] : 0.f; msh[j] = (MODE == 1 || MODE == 3) ? mb[cg * VE + j] : 0.f;
+    msc1[j] = MODE == 3 ? ms1[cg * VE + j] : 0.f; msh1[j] = MODE == 3 ? mb1[cg * VE + j] : 0.f;
+  }
   float acc[1 + NY][VE];
 #pragma unroll
   for (int q = 0; q < 1 + NY; ++q)
@@ -264,6 +269,7 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __rest
       bool on = true;
       if (MODE == 0) on = o[j] > 0.f;
       if (MODE == 1) on = (a0[j] * msc[j] + msh[j]) > 0.f;
+      if (MODE == 3) { float x = a0[j] * msc[j] + msh[j]; x += a1[j] * msc1[j] + msh1[j]; on = x > 0.f; }
       const float gg = on ? g[j] : 0.f;
       acc[0][j] += gg;
       acc[1][j] += gg * a0[j];
@@ -274,8 +280,8 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __rest
 }
 
 template <typename T>
-static int launch_bn_bwd_reduce_t(const void* dout, const void* out, const float* ms, const float* mb, const void* y0,
-                                  const void* y1, long npix, int C, float* partials, hipStream_t s) {
+static int launch_bn_bwd_reduce_t(const void* dout, const void* out, const float* ms, const float* mb, const float* ms1,
+                                  const float* mb1, const void* y0, const void* y1, long npix, int C, float* partials, hipStream_t s) {
   constexpr int VE = Elem<T>::kVec;
   if (C % VE) { set_error("bn_bwd_reduce: C=%d not a multiple of %d", C, VE); return MMVAE_ERR_UNSUPPORTED; }
   const int cvecs = C / VE, threads = block_threads_for(cvecs);
@@ -284,19 +290,20 @@ static int launch_bn_bwd_reduce_t(const void* dout, const void* out, const float
   if (blocks > 1024) blocks = 1024;
   const int ny = y1 ? 2 : 1;
   const size_t sm = (size_t)threads * (1 + ny) * VE * sizeof(float);
-  const int mode = out ? 0 : (ms ? 1 : 2);
+  const int mode = out ? 0 : (ms ? ((ms1 && ny == 2) ? 3 : 1) : 2);
 #define MMVAE_LAUNCH(NY, MODE) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, NY, MODE>), dim3(blocks), dim3(threads), sm, s, \
-    (const T*)dout, (const T*)out, ms, mb, (const T*)y0, (const T*)y1, nvec, C, partials)
-  if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else MMVAE_LAUNCH(2, 2); }
+    (const T*)dout, (const T*)out, ms, mb, ms1, mb1, (const T*)y0, (const T*)y1, nvec, C, partials)
+  if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else if (mode == 3) MMVAE_LAUNCH(2, 3); else MMVAE_LAUNCH(2, 2); }
   else { if (mode == 0) MMVAE_LAUNCH(1, 0); else if (mode == 1) MMVAE_LAUNCH(1, 1); else MMVAE_LAUNCH(1, 2); }
 #undef MMVAE_LAUNCH
   int rc = check_launch("bn_bwd_reduce");
   return rc ? rc : blocks;
 }
 int launch_bn_bwd_reduce(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
-                         const void* y0, const void* y1, long npix, int C, float* partials, hipStream_t s) {
-  return dt == DT_F32 ? launch_bn_bwd_reduce_t<float>(dout, out, msk_scale, msk_shift, y0, y1, npix, C, partials, s)
-                      : launch_bn_bwd_reduce_t<bf16_t>(dout, out, msk_scale, msk_shift, y0, y1, npix, C, partials, s);
+                         const void* y0, const void* y1, long npix, int C, float* partials, hipStream_t s,
+                         const float* msk_scale1, const float* msk_shift1) {
+  return dt == DT_F32 ? launch_bn_bwd_reduce_t<float>(dout, out, msk_scale, msk_shift, msk_scale1, msk_shift1, y0, y1, npix, C, partials, s)
+                      : launch_bn_bwd_reduce_t<bf16_t>(dout, out, msk_scale, msk_shift, msk_scale1, msk_shift1, y0, y1, npix, C, partials, s);
 }
 
 __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
@@ -334,18 +341,20 @@ int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
 
 template <typename T, int NY, int MODE>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const float* __restrict__ ms,
-                                    const float* __restrict__ mb, const T* __restrict__ y0, const float* __restrict__ A0,
+                                    const float* __restrict__ mb, const float* __restrict__ ms1, const float* __restrict__ mb1,
+                                    const T* __restrict__ y0, const float* __restrict__ A0,
                                     const float* __restrict__ B0, const float* __restrict__ C0, T* __restrict__ dy0,
                                     const T* __restrict__ y1, const float* __restrict__ A1, const float* __restrict__ B1,
                                     const float* __restrict__ C1, T* __restrict__ dy1, long nvec, int C) {
   constexpr int VE = Elem<T>::kVec;
   const int cvecs = C / VE;
   const int cg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % cvecs);
-  float msc[VE], msh[VE], a0[VE], b0[VE], c0[VE], a1[VE], b1[VE], c1[VE];
+  float msc[VE], msh[VE], msc1[VE], msh1[VE], a0[VE], b0[VE], c0[VE], a1[VE], b1[VE], c1[VE];
 #pragma unroll
   for (int j = 0; j < VE; ++j) {
     const int ch = cg * VE + j;
-    msc[j] = MODE == 1 ? ms[ch] : 0.f; msh[j] = MODE == 1 ? mb[ch] : 0.f;
+    msc[j] = (MODE == 1 || MODE == 3) ? ms[ch] : 0.f; msh[j] = (MODE == 1 || MODE == 3) ? mb[ch] : 0.f;
+    msc1[j] = MODE == 3 ? ms1[ch] : 0.f; msh1[j] = MODE == 3 ? mb1[ch] : 0.f;
     a0[j] = A0[ch]; b0[j] = B0[ch]; c0[j] = C0[ch];
     a1[j] = NY == 2 ? A1[ch] : 0.f; b1[j] = NY == 2 ? B1[ch] : 0.f; c1[j] = NY == 2 ? C1[ch] : 0.f;
   }
@@ -361,6 +370,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
       bool on = true;
       if (MODE == 0) on = o[j] > 0.f;
       if (MODE == 1) on = (f0[j] * msc[j] + msh[j]) > 0.f;
+      if (MODE == 3) { float x = f0[j] * msc[j] + msh[j]; x += f1[j] * msc1[j] + msh1[j]; on = x > 0.f; }
       const float gg = on ? g[j] : 0.f;
       r0[j] = a0[j] * gg + b0[j] * f0[j] + c0[j];
       if (NY == 2) r1[j] = a1[j] * gg + b1[j] * f1[j] + c1[j];
@@ -371,7 +381,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restr
 }
 
 template <typename T>
-static int launch_bn_bwd_apply_t(const void* dout, const void* out, const float* ms, const float* mb, const void* y0,
+static int launch_bn_bwd_apply_t(const void* dout, const void* out, const float* ms, const float* mb, const float* ms1, const float* mb1,
+                                 const void* y0,
                                  const float* A0, const float* B0, const float* C0, void* dy0, const void* y1, const float* A1,
                                  const float* B1, const float* C1, void* dy1, long npix, int C, hipStream_t s) {
   constexpr int VE = Elem<T>::kVec;
@@ -380,10 +391,10 @@ static int launch_bn_bwd_apply_t(const void* dout, const void* out, const float*
   const long nvec = npix * cvecs;
   const int blocks = elem_blocks(nvec, threads);
   const int ny = y1 ? 2 : 1;
-  const int mode = out ? 0 : (ms ? 1 : 2);
+  const int mode = out ? 0 : (ms ? ((ms1 && ny == 2) ? 3 : 1) : 2);
 #define MMVAE_LAUNCH(NY, MODE) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, NY, MODE>), dim3(blocks), dim3(threads), 0, s, \
-    (const T*)dout, (const T*)out, ms, mb, (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, nvec, C)
-  if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else MMVAE_LAUNCH(2, 2); }
+    (const T*)dout, (const T*)out, ms, mb, ms1, mb1, (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, nvec, C)
+  if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else if (mode == 3) MMVAE_LAUNCH(2, 3); else MMVAE_LAUNCH(2, 2); }
   else { if (mode == 0) MMVAE_LAUNCH(1, 0); else if (mode == 1) MMVAE_LAUNCH(1, 1); else MMVAE_LAUNCH(1, 2); }
 #undef MMVAE_LAUNCH
   return check_launch("bn_bwd_apply");
@@ -391,9 +402,9 @@ static int launch_bn_bwd_apply_t(const void* dout, const void* out, const float*
 int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
                         const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
                         const void* y1, const float* A1, const float* B1, const float* C1, void* dy1,
-                        long npix, int C, hipStream_t s) {
-  return dt == DT_F32 ? launch_bn_bwd_apply_t<float>(dout, out, msk_scale, msk_shift, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, npix, C, s)
-                      : launch_bn_bwd_apply_t<bf16_t>(dout, out, msk_scale, msk_shift, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, npix, C, s);
+                        long npix, int C, hipStream_t s, const float* msk_scale1, const float* msk_shift1) {
+  return dt == DT_F32 ? launch_bn_bwd_apply_t<float>(dout, out, msk_scale, msk_shift, msk_scale1, msk_shift1, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, npix, C, s)
+                      : launch_bn_bwd_apply_t<bf16_t>(dout, out, msk_scale, msk_shift, msk_scale1, msk_shift1, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, npix, C, s);
 }
 
 // ---------------------------------------------------------------- NCHW f32 elementwise (output BN)

@@ -148,7 +148,8 @@ int launch_affine_act(int dt, const void* a, const float* sa, const float* ba, i
 // BN-backward reductions.  g = dout * mask, mask = (out > 0) if out!=null else (y0*msk_scale+msk_shift > 0) if msk_scale else 1.
 // partials [nparts][1+NY][C]: sum g, sum g*y0, (sum g*y1).  Returns nparts.
 int launch_bn_bwd_reduce(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
-                         const void* y0, const void* y1, long npix, int C, float* partials, hipStream_t s);
+                         const void* y0, const void* y1, long npix, int C, float* partials, hipStream_t s,
+                         const float* msk_scale1 = nullptr, const float* msk_shift1 = nullptr);   // both masks: join recomputed
 // coefficients for dy = A*g + B*y + Cc, plus dgamma/dbeta (accumulated into grads with +=)
 struct BnBwdFinalizeArgs {
   const float* partials; int nparts; int C; int which /*0: y0, 1: y1*/; int ny; double count;
@@ -159,7 +160,7 @@ int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
 int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
                         const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
                         const void* y1, const float* A1, const float* B1, const float* C1, void* dy1,
-                        long npix, int C, hipStream_t s);
+                        long npix, int C, hipStream_t s, const float* msk_scale1 = nullptr, const float* msk_shift1 = nullptr);
 // NCHW f32 variants for the output BatchNorm (decoder.bn2): recon = raw*scale+shift ; backward pieces
 int launch_affine_nchw(const float* raw, const float* scale, const float* shift, float* out, int N, int C, int HW, hipStream_t s);
 int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s);

@@ -394,13 +394,14 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     const float* xs = i == 0 ? bnf(bn0, base, 2) : nullptr;
     const float* xb = i == 0 ? bnf(bn0, base, 3) : nullptr;
     // join backward: g = d_out * [out > 0] feeds bn2 (y2) and the shortcut BN (ys)
-    int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, base + B.ys, npix, B.C, part, s);
+    int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npix, B.C, part, s,
+                                  bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, cnt, s));
     MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, cnt, s));
-    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
                                bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                               base + P.dys, npix, B.C, s));
+                               base + P.dys, npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
     MM_TRY(run_wgrad(B.c2, N, base + P.dy2, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
                      bnf(B.b1, base, 3), grads, s));
@@ -552,13 +553,14 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     const void* xin = i == 0 ? base + P.y0d : base + dec[i - 1].out;
     const float* xs = i == 0 ? bnf(dbn0, base, 2) : nullptr;
     const float* xb = i == 0 ? bnf(dbn0, base, 3) : nullptr;
-    np = launch_bn_bwd_reduce(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, base + B.ys, npo, B.C, part, s);
+    np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
+                              bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
     MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, (double)npo, s));
-    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], base + B.out, nullptr, nullptr, base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
+    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
                                bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                               base + P.dys, npo, B.C, s));
+                               base + P.dys, npo, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
     MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2, B.Hout, B.Wout, nullptr,
                      nullptr, grads, s));
