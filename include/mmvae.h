@@ -112,6 +112,10 @@ MMVAE_API int mmvae_loss_finish(const double* acc, float* out, float nll, float 
 /* ------------------------------------------------------------------ train-step plumbing
  * (label - mean)/std, main.py:383-387.  labels int64 [n]; image f32 [n]. */
 MMVAE_API int mmvae_normalise_labels(const int64_t* labels, int64_t n, float mean, float stdv, float* image, void* stream);
+/* Input pipeline on device: uint8 pixel -> x/255 -> nearest of q k-means centres (kmeans.predict, main.py:25,
+ * utils.py:279-309; lowest index wins ties) -> labels int64 (may be NULL) and image = (label-mean)/std f32 (may be NULL). */
+MMVAE_API int mmvae_quantise_normalise(const uint8_t* frames, int64_t n, const float* centres, int q, float mean, float stdv,
+                             int64_t* labels, float* image, void* stream);
 /* torch.optim.Adam defaults (main.py:468) over a flat buffer: bc1 = 1-beta1^t, bc2_sqrt = sqrt(1-beta2^t);
  * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
 MMVAE_API int mmvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "mmvae_mmd_bwd": (c_int, [P, P, c_int, c_int, c_float, P, P, P]),
     "mmvae_loss_finish": (c_int, [P, P, c_float, c_float, c_float, c_float, P]),
     "mmvae_normalise_labels": (c_int, [P, c_int64, c_float, c_float, P, P]),
+    "mmvae_quantise_normalise": (c_int, [P, c_int64, P, c_int, c_float, c_float, P, P, P]),
     "mmvae_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
     "mmvae_conv2d_fwd": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "mmvae_conv2d_dgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -122,6 +122,10 @@ int mmvae_loss_finish(const double* acc, float* out, float nll, float kl_coef, f
 int mmvae_normalise_labels(const int64_t* labels, int64_t n, float mean, float stdv, float* image, void* st) {
   return launch_normalise(DT_F32, reinterpret_cast<const long long*>(labels), (long)n, mean, stdv, nullptr, image, S(st));
 }
+int mmvae_quantise_normalise(const uint8_t* frames, int64_t n, const float* centres, int q, float mean, float stdv, int64_t* labels,
+                             float* image, void* st) {
+  return launch_quantise_normalise(frames, (long)n, centres, q, mean, stdv, reinterpret_cast<long long*>(labels), image, S(st));
+}
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1,
                     float bc2_sqrt, float grad_scale, void* st) {
   AdamArgs a{p, g, m, v, (long)n, lr, b1, b2, eps, wd, bc1, bc2_sqrt, grad_scale};

@@ -193,6 +193,8 @@ struct AdamArgs { float* p; const float* g; float* m; float* v; long n; float lr
 int launch_adam(const AdamArgs& a, hipStream_t s);
 // labels (int64) -> image T [(l - mean)/std] (+ f32 copy for the Gaussian target)
 int launch_normalise(int dt, const long long* labels, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s);
+int launch_quantise_normalise(const unsigned char* frames, long n, const float* centres, int q, float mean, float stdv,
+                              long long* labels, float* image, hipStream_t s);
 int launch_convert(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s);
 int launch_concat2_to_t(int dt, const float* a, const float* b, int rows, int ca, int cb, void* out, hipStream_t s);
 int launch_loss_finish(const double* acc, float* out, float nll, float klc, float mmdc, float n, hipStream_t s);

@@ -385,6 +385,27 @@ int launch_normalise(int dt, const long long* labels, long n, float mean, float 
   return check_launch("normalise");
 }
 
+// k-means quantiser of the input pipeline (main.py:21-38: ToTensor -> kmeans.predict per pixel; utils.py:279-309) fused with
+// the normalisation of main.py:383-387: label = argmin_k (x/255 - centre_k)^2 (lowest index wins ties), image = (label-mean)/std
+__global__ void quantise_normalise_kernel(const unsigned char* __restrict__ frames, long n, const float* __restrict__ centres, int q,
+                                          float mean, float stdv, long long* __restrict__ labels, float* __restrict__ image) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = (float)frames[i] / 255.0f;
+    int best = 0;
+    float bd = (x - centres[0]) * (x - centres[0]);
+    for (int k = 1; k < q; ++k) { const float d = (x - centres[k]) * (x - centres[k]); if (d < bd) { bd = d; best = k; } }
+    if (labels) labels[i] = best;
+    if (image) image[i] = ((float)best - mean) / stdv;
+  }
+}
+int launch_quantise_normalise(const unsigned char* frames, long n, const float* centres, int q, float mean, float stdv,
+                              long long* labels, float* image, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  if (q < 1 || q > 256) { set_error("quantise: q=%d out of range", q); return MMVAE_ERR_ARG; }
+  hipLaunchKernelGGL(quantise_normalise_kernel, dim3(rblocks(n, 2048)), dim3(256), 0, s, frames, n, centres, q, mean, stdv, labels, image);
+  return check_launch("quantise_normalise");
+}
+
 template <typename TI, typename TOo>
 __global__ void convert_kernel(const TI* __restrict__ in, TOo* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)

@@ -76,3 +76,91 @@ def train(model, data_loader, optimizer, device, args, epoch=0, data_mean=0, dat
         print("Epoch={:d}; Loss={:0.5f} NLL={:.3f}; KL={:.3f}; MMD={:.3f}; time_tr={:.1f}s;".format(
             epoch, np.mean(losses), np.mean(nlls), np.mean(kls), np.mean(mmds), elapsed))
     return losses, nlls, kls, mmds
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Drop-in contract around the loop: model-name grammar, checkpoint format, device-side input quantisation
+# ---------------------------------------------------------------------------------------------------------------------
+def _is_number(text) -> bool:
+    try:
+        float(text)
+        return True
+    except ValueError:
+        return False
+
+
+def select_model(args):
+    """Model factory with the reference's name grammar and keyword mapping (main.py:41-147) for the VAE family:
+    ``<normal|categorical>_vae_<kl>_kl_<mmd>_mmd``.  Returns ``(model, model_params)`` with the reference's dict keys.
+    ``pixelcnn_<n>`` and ``*_pixelvae_*`` names raise NotImplementedError (PixelCNN is out of scope)."""
+    from .model import VAE
+    parts = args.model.split("_")
+    if len(parts) == 2:
+        if parts[0] != "pixelcnn" or not _is_number(parts[1]):
+            raise AssertionError("It has to be only pixelcnn_2/4/7")
+        raise NotImplementedError("pixelcnn_<n> models are not built (PixelCNN is out of scope)")
+    if not (len(parts) == 6 and parts[1] in ("vae", "pixelvae") and parts[3] == "kl" and parts[5] == "mmd"):
+        raise AssertionError("model name should be of the format normal_vae_1_kl_10_mmd")
+    if not (_is_number(parts[2]) and _is_number(parts[4])):
+        raise AssertionError("coefficients should be numeric")
+    if parts[1] == "pixelvae":
+        raise NotImplementedError("*_pixelvae_* models are not built (PixelCNN is out of scope)")
+    is_normal = parts[0] == "normal"
+    if is_normal and args.sigma_decoder == 0:                      # main.py:91-93
+        raise AssertionError("sigma_decoder should be non-zero for normal_vae_* models")
+    mp = {"model_name": "VAE", "is_decoder_out_normal": is_normal, "only_pixelcnn": False, "use_pixelcnn": False,
+          "coeff_kl": float(parts[2]), "coeff_mmd": float(parts[4]),
+          "input_channels": args.input_channels, "input_image_size": args.input_image_size,
+          "intermediate_channels": args.intermediate_channels, "z_dimension": args.z_dimension,
+          "sigma_decoder": args.sigma_decoder, "require_rsample": args.require_rsample,
+          "num_pixelcnn_layers": getattr(args, "num_pixelcnn_layers", 4),
+          "pixelcnn_activation": getattr(args, "pixelcnn_activation", "ReLu"), "coeff_nll": args.nll,
+          "pixelcnn_out_channels": 0}
+    # Gaussian decoder: as many channels as the input; categorical: one per quantisation level (main.py:124-132)
+    mp["decoder_out_channels"] = mp["input_channels"] if is_normal else int(args.quantization)
+    model = VAE(in_channels=mp["input_channels"], intermediate_channels=mp["intermediate_channels"],
+                decoder_out_channels=mp["decoder_out_channels"], pixelcnn_out_channels=mp["pixelcnn_out_channels"],
+                z_dimension=mp["z_dimension"], pixelcnn=False, only_pixelcnn=False,
+                pixelcnn_layers=mp["num_pixelcnn_layers"], pixelcnn_activation=mp["pixelcnn_activation"],
+                nll=mp["coeff_nll"], kl=mp["coeff_kl"], mmd=mp["coeff_mmd"], require_rsample=mp["require_rsample"],
+                sigma_decoder=mp["sigma_decoder"], input_image_size=mp["input_image_size"])
+    return model, mp
+
+
+def save_checkpoint(model, optimizer, epoch, directory):
+    """Same file and dict layout as main.py:522-526 (``latest-model.model`` = {'epoch','state_dict','optimizer'}), so
+    checkpoints move between the reference and this package in both directions."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    path = os.path.join(directory, "latest-model.model")
+    torch.save({"epoch": epoch, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}, path)
+    return path
+
+
+def load_checkpoint(path, model, optimizer=None, map_location=None):
+    """The resume path the reference lacks: restores parameters / BN buffers (and Adam moments for FusedAdam or
+    torch.optim.Adam); returns the stored epoch."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    model.load_state_dict(ck["state_dict"])
+    if optimizer is not None and "optimizer" in ck:
+        loader = getattr(optimizer, "load_flat_state", None)
+        if loader is not None:
+            loader(ck["optimizer"])
+        else:
+            optimizer.load_state_dict(ck["optimizer"])
+    return ck.get("epoch", 0)
+
+
+def quantise_frames(frames_u8, centres, data_mean, data_std):
+    """Device-side input pipeline: uint8 frames -> k-means labels (int64) and normalised f32 image, one
+    kernel (replaces ToTensor + kmeans.predict on the host, main.py:21-38, and the normalisation of main.py:383-387)."""
+    from ._lib import check, lib, ptr
+    f = frames_u8.contiguous()
+    if f.dtype != torch.uint8 or not f.is_cuda:
+        raise ValueError("quantise_frames expects a uint8 tensor on the GPU")
+    c = torch.as_tensor(centres, dtype=torch.float32, device=f.device).contiguous()
+    labels = torch.empty(f.shape, dtype=torch.int64, device=f.device)
+    image = torch.empty(f.shape, dtype=torch.float32, device=f.device)
+    check(lib().mmvae_quantise_normalise(ptr(f), f.numel(), ptr(c), c.numel(), float(data_mean), float(data_std), ptr(labels),
+                                         ptr(image), torch.cuda.current_stream().cuda_stream), "mmvae_quantise_normalise")
+    return labels, image

@@ -555,6 +555,28 @@ class FusedAdam(torch.optim.Optimizer):
         return G
 
     @torch.no_grad()
+    def load_flat_state(self, state_dict):
+        """Resume from a torch.optim.Adam-layout state_dict (this class's own or the reference's ``optimizer`` entry)."""
+        model = self._model()
+        model._ensure_flat()
+        m, v = self._moments(model)
+        st = state_dict.get("state", {})
+        for i, (_, p, off, n, shp) in enumerate(model._ptable):
+            e = st.get(i)
+            if e is None:
+                continue
+            m[off:off + n].copy_(e["exp_avg"].reshape(-1).to(m.device))
+            v[off:off + n].copy_(e["exp_avg_sq"].reshape(-1).to(v.device))
+            self._t = int(float(e["step"]))
+        for st_ in self.state.values():
+            st_["step"] = torch.tensor(float(self._t))
+        if state_dict.get("param_groups"):
+            g = state_dict["param_groups"][0]
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in g:
+                    self.param_groups[0][k] = g[k]
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         model = self._model()
