@@ -167,8 +167,19 @@ int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, fl
   const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
   const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
   (void)numel_w;
-  if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st));
-  return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st));
+  // partial-image scratch of the single-op entry point: one lazily allocated buffer per device, kept for the process
+  // lifetime (calls on different streams of one device must not overlap; the Net entry points use their own workspace)
+  static float* scratch[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { set_error("conv2d_wgrad: no current device"); return MMVAE_ERR_HIP; }
+  if (!scratch[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, kWgradScratchBytes);
+    if (e != hipSuccess) { set_error("conv2d_wgrad: hipMalloc scratch: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
+    scratch[dev] = static_cast<float*>(p);
+  }
+  if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st), scratch[dev]);
+  return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), scratch[dev]);
 }
 int mmvae_convert(int di, int dout, const void* in, void* out, int64_t n, void* st) { return launch_convert(di, dout, in, out, (long)n, S(st)); }
 

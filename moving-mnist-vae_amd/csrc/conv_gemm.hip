@@ -532,9 +532,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
 // Returns 1 when the v2 kernel ran, 0 when not eligible, <0 on error.
 static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
-  const bool boundary = a.P_planar || a.G_planar;
-  if ((conv_force_v1() && !boundary) || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
-  if ((a.P_planar && a.Ca != 16) || (a.G_planar && a.Cb != 16)) return 0;
+  if (conv_force_v1() || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
   auto pick = [](int c) { return c >= 64 ? 64 : c; };
   const int TA = pick(a.Ca), TB = pick(a.Cb);
   if (!(TA == 16 || TA == 32 || TA == 64) || !(TB == 16 || TB == 32 || TB == 64)) return 0;
@@ -546,47 +544,49 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   b.proG_scale = a.proG_scale; b.proG_shift = a.proG_shift; b.proG_relu = a.proG_relu;
   b.TG = wgrad2_taps_per_block(ta16, tb16, a.ntaps);
   bool fits = false;
-  for (int sub = 1; sub > 1 && !fits; sub >>= 1) {       // (disabled: larger tiles cost more in occupancy than they save in barriers)
-    if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, 128, sub)) continue;
-    fits = b.g.ntiles >= 1024 && wgrad2_lds_bytes(b, dt, TA, TB) <= kV2MaxLds;
-  }
-  for (int TP = 128; TP >= 32 && !fits; TP >>= 1) {     // else shrink the pixel tile until patch + P tile fit in LDS
+  size_t lds = 0;
+  for (int TP = 128; TP >= 32 && !fits; TP >>= 1) {     // shrink the pixel tile until patch + P tile fit in LDS
     if (TP < 128 && a.ntaps < 4) break;                 // the k-split mode (1x1 convs) needs all four k-steps
     if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, TP, 1)) continue;
-    fits = wgrad2_lds_bytes(b, dt, TA, TB) <= kV2MaxLds;
+    lds = wgrad2_lds_bytes(b, dt, TA, TB);
+    fits = lds <= kV2MaxLds && wgrad2_patch_slots(b, dt, TB) <= 16;
   }
   if (!fits) return 0;
   b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.Ca_valid = a.Ca_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
-  b.P_planar = a.P_planar; b.P_planes = a.P_planes; b.G_planar = a.G_planar; b.G_planes = a.G_planes;
   b.sA = a.sA; b.sB = a.sB; b.scale = a.scale;
   for (int t = 0; t < 25; ++t) b.tap_off[t] = a.tap_off[t];
   const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
   const int zg = (a.ntaps + b.TG - 1) / b.TG;
-  int gx = 1024 / (tiles_ab * zg); if (gx < 1) gx = 1;
   const long wsize = (long)a.Ca * a.Cb * a.ntaps;
-  const bool via_scratch = a.scratch != nullptr && wsize >= 32768;
-  if (via_scratch) {
-    // Large gradients: every persistent block flushes its dW tile with float atomics.  Straight into the PyTorch layout
-    // those are scattered (stride k*k) and slow, which used to cap the grid at ~1 block per CU.  Reduce into a
-    // [tap][a][b] scratch image instead (256-byte contiguous atomic rows run at the full atomic rate), then un-permute.
-    hipError_t e = hipMemsetAsync(a.scratch, 0, (size_t)wsize * sizeof(float), s);
-    if (e != hipSuccess) { set_error("wgrad: memset scratch: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
-    b.dW = a.scratch; b.sA = a.Cb; b.sB = 1; b.scale = 1.f; b.flush_per_tap = 1;
-    for (int t = 0; t < a.ntaps; ++t) b.tap_off[t] = t * a.Ca * a.Cb;
+  // grid: as many persistent blocks as the CUs can hold (LDS-limited), each flushing one partial image tile
+  int occ = (int)((160 * 1024) / lds); if (occ > 6) occ = 6; if (occ < 1) occ = 1;
+  static const int occ_env = [] { const char* e = getenv("MMVAE_WGRAD_OCC"); return e ? atoi(e) : 0; }();
+  if (occ_env > 0) occ = occ_env;
+  long gx = (256L * occ) / ((long)tiles_ab * zg); if (gx < 1) gx = 1;
+  const bool partial = a.scratch != nullptr;
+  if (partial) {
+    // keep the partial images (written once, read once) below the bytes of the operands themselves
+    const long in_bytes = ((long)a.N * a.Hp * a.Wp * a.Ca + (long)a.N * a.Hg * a.Wg * a.Cb) * (long)dtype_size(dt);
+    long budget = in_bytes > (8L << 20) ? in_bytes : (8L << 20);
+    if (budget > (long)kWgradScratchBytes) budget = (long)kWgradScratchBytes;
+    const long cap = budget / (wsize * 4);
+    if (cap < 1) return 0;
+    if (gx > cap) gx = cap;
   } else {                                              // direct flush: keep the scattered atomics of a launch below ~3M
     long cap = (3L << 20) / (wsize > 0 ? wsize : 1);
     if (cap < 2) cap = 2;
-    if (gx > cap) gx = (int)cap;
+    if (gx > cap) gx = cap;
   }
   if (gx > b.g.ntiles) gx = b.g.ntiles;
-  const int rc = launch_wgrad2(dt, b, gx, tiles_ab, zg, ta16, tb16, s);
+  if (partial) { b.dW = a.scratch; b.partial = 1; }
+  const int rc = launch_wgrad2(dt, b, (int)gx, tiles_ab, zg, ta16, tb16, s);
   if (rc < 0) return rc;
-  if (via_scratch) {
-    UnpermuteArgs u; memset(&u, 0, sizeof(u));
-    u.scratch = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid;
-    u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
+  if (partial) {
+    WgradReduceArgs u; memset(&u, 0, sizeof(u));
+    u.part = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.nparts = (int)gx;
+    u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid; u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
     for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
-    const int rc2 = launch_wgrad_unpermute(u, s);
+    const int rc2 = launch_wgrad_reduce(u, s);
     if (rc2 < 0) return rc2;
   }
   return 1;
@@ -605,7 +605,6 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   {
     const int rc2 = try_wgrad2(dt, a, s);
     if (rc2 != 0) return rc2 < 0 ? rc2 : MMVAE_OK;
-    if (a.P_planar || a.G_planar) { set_error("wgrad: planar boundary layouts need the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }
   }
   const int TA = a.Ca >= 64 ? 64 : ((a.Ca + 15) / 16) * 16;
   const int TB = a.Cb >= 64 ? 64 : ((a.Cb + 15) / 16) * 16;

@@ -13,41 +13,9 @@
 //     byte offset.  Accumulators live in registers across the persistent loop; the flush goes through LDS so
 //     that global float atomics are issued on consecutive addresses (256 B per wave instruction).
 #include "kernels.hpp"
+#include "tile_common.hpp"
 
 namespace mmvae {
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-__device__ __forceinline__ f32x4 mma_bf16(const Vec16& a, const Vec16& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mma_f32v(const Vec16& a, const Vec16& b, f32x4 c) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w[j]), __uint_as_float(b.w[j]), c, 0, 0, 0);
-  return c;
-}
-template <typename T> __device__ __forceinline__ f32x4 mma_vec(const Vec16& a, const Vec16& b, f32x4 c);
-template <> __device__ __forceinline__ f32x4 mma_vec<bf16_t>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_bf16(a, b, c); }
-template <> __device__ __forceinline__ f32x4 mma_vec<float>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_f32v(a, b, c); }
-
-__device__ __forceinline__ void tile_origin(const TileGeom& g, int tile, int seg, int& n, int& hq0) {
-  if (g.tiles_per_img > 0) {
-    n = tile / g.tiles_per_img;
-    hq0 = (tile - n * g.tiles_per_img) * g.qr;
-  } else {
-    n = tile * g.segs + seg;
-    hq0 = 0;
-  }
-}
-
-// patch pixel index (origin-relative, in pixels) of tile pixel p; p must be < segs*qr*Wq
-__device__ __forceinline__ int patch_index(const TileGeom& g, int p) {
-  const int per_seg = g.qr * g.Wq;
-  const int seg = p / per_seg, rem = p - seg * per_seg;
-  const int j = rem / g.Wq, wq = rem - j * g.Wq;
-  return (seg * g.PR + j * g.SI) * g.PW + wq * g.SI;
-}
 
 // Stage the patch of `Cs` channels [c0, c0+Cs) of X (tensor channels C) into LDS: layout [segs*PR][PW][Cs].
 // Loads are issued in register batches of NB (all NB in flight, then NB LDS stores): staging is latency-bound.
@@ -352,318 +320,6 @@ int launch_gather2(int dt, int out_dt, const Gather2Args& a, int gx, hipStream_t
   if (dt == DT_F32) return launch_gather2_t<float, float>(a, dt, gx, s);
   if (out_dt == DT_F32) return launch_gather2_t<bf16_t, float>(a, dt, gx, s);
   return launch_gather2_t<bf16_t, bf16_t>(a, dt, gx, s);
-}
-
-// ============================================================================ wgrad2
-template <typename T> struct FragOps;
-template <> struct FragOps<bf16_t> {
-  // lane (g = lane>>4, i = lane&15): 8 pixels = two 4-pixel blocks; lane supplies the address of pixel-row q = i>>2,
-  // channel quad p = i&3 of its group's block and receives channel i of the 4 pixels (ds_read_b64_tr_b16).
-  static constexpr int kSteps = 1;       // MFMA k-steps per 32-pixel wave slice
-  __device__ static __forceinline__ Vec16 load(const char* base, int off0, int off1) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
-    Vec16 v;
-    v.w[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-    v.w[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-    v.w[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-    v.w[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
-    return v;
-  }
-};
-
-// LDS carve: [P tile: TP x TA][G patch: rows x PW x TB][sToff: 32 ints][sProP 1024 f][sProG 1024 f]; the accumulator
-// staging buffer of the flush aliases the front of the region.
-// Work split over the 4 waves of a block:
-//   TS = true  (>= 4 taps): wave w owns taps w, w+4, ... of the block's tap group and runs all four 32-pixel k-steps of
-//                           the tile -> only MAXT*TA16*TB16 accumulator tiles per wave (registers -> occupancy);
-//   TS = false (1x1 convs): wave w owns k-step w of the tile and every tap.
-template <int TA16, int TB16> struct Wgrad2Cfg {
-  static constexpr int kUnits = TA16 * TB16;
-  static constexpr int kMaxT = (12 / kUnits) < 1 ? 1 : ((12 / kUnits) > 4 ? 4 : (12 / kUnits));
-};
-
-template <typename T, int TA16, int TB16, bool TS>
-__global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
-  constexpr int VE = Elem<T>::kVec;
-  constexpr int ES = sizeof(T);
-  constexpr int TA = TA16 * 16, TB = TB16 * 16;
-  constexpr int MAXT = Wgrad2Cfg<TA16, TB16>::kMaxT;
-  constexpr int NKS = TS ? 4 : 1;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const TileGeom g = a.g;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, r = lane & 15;
-  const int nb_tiles = (a.Cb + TB - 1) / TB;
-  const int a0 = (blockIdx.y / nb_tiles) * TA, b0 = (blockIdx.y % nb_tiles) * TB;
-  const int tap0 = blockIdx.z * a.TG;
-  const int tg_n = min(a.TG, a.ntaps - tap0);
-  char* sP = smem;                                                     // [128][TA]
-  char* sG = sP + g.TP * TA * ES;                                      // patch
-  const int patch_bytes = g.segs * g.PR * g.PW * TB * ES;
-  int* sToff = reinterpret_cast<int*>(sG + patch_bytes);
-  float* sProP = reinterpret_cast<float*>(sToff + 32);
-  float* sProG = sProP + 1024;
-  const T* __restrict__ Pp = reinterpret_cast<const T*>(a.P);
-  const T* __restrict__ Gp = reinterpret_cast<const T*>(a.G);
-  const bool proP = a.proP_scale != nullptr, proG = a.proG_scale != nullptr;
-  if (t < tg_n) {
-    const int tap = tap0 + t, kh = tap / a.ksz, kw = tap - kh * a.ksz;
-    sToff[t] = (kh * g.PW + kw) * TB * ES;          // patch origin is (q*SI - pad): tap (kh,kw) sits at +kh rows, +kw cols
-  }
-  if (proP) for (int i = t; i < TA; i += 256) {
-    const bool ok = a0 + i < a.Ca;
-    sProP[i] = ok ? a.proP_scale[a0 + i] : 0.f; sProP[512 + i] = ok ? a.proP_shift[a0 + i] : 0.f;
-  }
-  if (proG) for (int i = t; i < TB; i += 256) {
-    const bool ok = b0 + i < a.Cb;
-    sProG[i] = ok ? a.proG_scale[b0 + i] : 0.f; sProG[512 + i] = ok ? a.proG_shift[b0 + i] : 0.f;
-  }
-  f32x4 acc[MAXT][TA16][TB16];
-#pragma unroll
-  for (int tl = 0; tl < MAXT; ++tl)
-#pragma unroll
-    for (int ta = 0; ta < TA16; ++ta)
-#pragma unroll
-      for (int tb = 0; tb < TB16; ++tb) acc[tl][ta][tb] = (f32x4){0, 0, 0, 0};
-  const int npix_sub = g.sub > 1 ? 128 : g.segs * g.qr * g.Wq;      // pixel slots of one sub-tile
-  constexpr int pv = TA / VE;
-  // tile-independent LDS offsets of this lane's fragment pixels (bf16: 2 four-pixel blocks per k-step)
-  int offP[NKS][2], offG[NKS][2];
-  if constexpr (sizeof(T) == 2) {
-#pragma unroll
-    for (int i = 0; i < NKS; ++i)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        int p = 32 * (TS ? i : wv) + 16 * b + 4 * gq + (r >> 2);
-        offP[i][b] = p * TA * ES + (r & 3) * 8;
-        if (p >= npix_sub) p = 0;                   // P rows beyond the tile are zero; any finite G value will do
-        offG[i][b] = patch_index(g, p) * TB * ES + (r & 3) * 8;
-      }
-  }
-  // this wave's taps (local index within the block's tap group)
-  int my_tap[MAXT];
-#pragma unroll
-  for (int tl = 0; tl < MAXT; ++tl) my_tap[tl] = TS ? wv + 4 * tl : tl;
-
-  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-    __syncthreads();
-    // ---- P tile: pixels of the tile are contiguous in memory
-    {
-      int n, hq0;
-      tile_origin(g, tile, 0, n, hq0);
-      const long m0 = ((long)n * g.Hq + hq0) * g.Wq;
-      const long mend = g.tiles_per_img > 0 ? ((long)n * g.Hq + min(g.Hq, hq0 + g.qr)) * g.Wq : (long)min(g.N, n + g.segs) * g.Hq * g.Wq;
-      const int nvalid = (int)(mend - m0);
-      if (a.P_planar) {
-        // P is planar f32 [N][P_planes][Hq][Wq] (the reconstruction gradient): 16 zero-padded channels per LDS pixel
-        const float* Pf = reinterpret_cast<const float*>(a.P);
-        const long plane = (long)g.Hq * g.Wq;
-        for (int pix = t; pix < g.TP; pix += 256) {
-          float f[16];
-#pragma unroll
-          for (int c = 0; c < 16; ++c) f[c] = 0.f;
-          if (pix < nvalid) {
-            const long m = m0 + pix;
-            const long nn = m / plane, rem = m - nn * plane;
-#pragma unroll
-            for (int c = 0; c < 16; ++c)
-              if (c < a.P_planes) f[c] = Pf[(nn * a.P_planes + c) * plane + rem];
-          }
-#pragma unroll
-          for (int k = 0; k < 16 / VE; ++k) reinterpret_cast<Vec16*>(sP)[pix * (16 / VE) + k] = Elem<T>::pack(f + k * VE);
-        }
-      } else
-      for (int v = t; v < g.TP * pv; v += 256) {
-        const int pix = v / pv, cv = v - pix * pv;
-        Vec16 q = Vec16{{0, 0, 0, 0}};
-        if (pix < nvalid && a0 + cv * VE < a.Ca) {
-          q = *reinterpret_cast<const Vec16*>(Pp + (m0 + pix) * a.Ca + a0 + cv * VE);
-          if (proP) {
-            float f[VE];
-            Elem<T>::unpack(q, f);
-#pragma unroll
-            for (int j = 0; j < VE; ++j) {
-              const float x = f[j] * sProP[cv * VE + j] + sProP[512 + cv * VE + j];
-              f[j] = a.proP_relu ? fmaxf(x, 0.f) : x;
-            }
-            q = Elem<T>::pack(f);
-          }
-        }
-        reinterpret_cast<Vec16*>(sP)[v] = q;
-      }
-    }
-    if (a.G_planar) stage_patch_planar<T, T>(g, tile, Gp, a.G_planes, 16, reinterpret_cast<Vec16*>(sG));
-    else stage_patch<T, 8>(g, tile, Gp, a.Cb, b0, TB, proG ? sProG : nullptr, a.proG_relu, reinterpret_cast<Vec16*>(sG));
-    __syncthreads();
-    const int nks_tile = g.sub > 1 ? 4 : (g.TP >> 5);  // 32-pixel k-steps per sub-tile (TS mode: 4, 2 or 1)
-   for (int sb = 0; sb < g.sub; ++sb) {
-    const int subP = sb * 128 * TA * ES, subG = sb * g.sub_pix * TB * ES;
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int i = 0; i < NKS; ++i) {
-        if (TS && i >= nks_tile) break;
-        Vec16 af[TA16];
-#pragma unroll
-        for (int ta = 0; ta < TA16; ++ta) af[ta] = FragOps<bf16_t>::load(sP, offP[i][0] + subP + ta * 32, offP[i][1] + subP + ta * 32);
-#pragma unroll
-        for (int tl = 0; tl < MAXT; ++tl) {
-          if (my_tap[tl] < tg_n) {
-            const int toff = sToff[my_tap[tl]];
-#pragma unroll
-            for (int tb = 0; tb < TB16; ++tb) {
-              const Vec16 bf = FragOps<bf16_t>::load(sG, offG[i][0] + subG + toff + tb * 32, offG[i][1] + subG + toff + tb * 32);
-#pragma unroll
-              for (int ta = 0; ta < TA16; ++ta) acc[tl][ta][tb] = mma_bf16(af[ta], bf, acc[tl][ta][tb]);
-            }
-          }
-        }
-      }
-    } else {
-      // ---- f32 (validation mode): 8 MFMA 16x16x4 steps per 32-pixel k-step; pixel of (step j, group gq): 32ks + 4j + gq
-      for (int i = 0; i < NKS; ++i) {
-        if (TS && i >= nks_tile) break;
-        const int ks = TS ? i : wv;
-        for (int j = 0; j < 8; ++j) {
-          int p = 32 * ks + 4 * j + gq;
-          const int oP = p * TA * ES + r * 4 + subP;
-          if (p >= npix_sub) p = 0;
-          const int oG = patch_index(g, p) * TB * ES + r * 4 + subG;
-          float av[TA16];
-#pragma unroll
-          for (int ta = 0; ta < TA16; ++ta) av[ta] = *reinterpret_cast<const float*>(sP + oP + ta * 64);
-#pragma unroll
-          for (int tl = 0; tl < MAXT; ++tl) {
-            if (my_tap[tl] < tg_n) {
-              const int toff = sToff[my_tap[tl]];
-#pragma unroll
-              for (int tb = 0; tb < TB16; ++tb) {
-                const float bv = *reinterpret_cast<const float*>(sG + oG + toff + tb * 64);
-#pragma unroll
-                for (int ta = 0; ta < TA16; ++ta)
-                  acc[tl][ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ta], bv, acc[tl][ta][tb], 0, 0, 0);
-              }
-            }
-          }
-        }
-      }
-    }
-   }
-  }
-  // ---- flush.  Preferred: combine the waves in LDS as [a_l][b_l][tap] (tap fastest) and issue global atomics on
-  // consecutive addresses.  When that image does not fit the block's LDS, go tap by tap through a [a_l][b_l] buffer.
-  __syncthreads();
-  float* sAcc = reinterpret_cast<float*>(smem);
-  const int nacc = TA * TB * tg_n;
-  if (!a.flush_per_tap && (size_t)nacc * 4 <= (size_t)a.lds_bytes) {
-    for (int i = t; i < nacc; i += 256) sAcc[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int tl = 0; tl < MAXT; ++tl) {
-      if (my_tap[tl] < tg_n) {
-#pragma unroll
-        for (int ta = 0; ta < TA16; ++ta)
-#pragma unroll
-          for (int tb = 0; tb < TB16; ++tb)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const int al = 16 * ta + 4 * gq + jj, bl = 16 * tb + r;
-              atomicAdd(&sAcc[(al * TB + bl) * tg_n + my_tap[tl]], acc[tl][ta][tb][jj]);
-            }
-      }
-    }
-    __syncthreads();
-    for (int i = t; i < nacc; i += 256) {
-      const int tl = i % tg_n, ab = i / tg_n;
-      const int bl = ab % TB, al = ab / TB;
-      if (a0 + al < a.Ca_valid && b0 + bl < a.Cb_valid)
-        atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tl], sAcc[i] * a.scale);
-    }
-  } else {
-#pragma unroll
-    for (int tl = 0; tl < MAXT; ++tl) {
-      for (int w = 0; w < (TS ? 4 : 1); ++w) {
-        const int tap_l = TS ? w + 4 * tl : tl;          // uniform over the block
-        if (tap_l >= tg_n) continue;
-        for (int i = t; i < TA * TB; i += 256) sAcc[i] = 0.f;
-        __syncthreads();
-        if (!TS || wv == w) {
-#pragma unroll
-          for (int ta = 0; ta < TA16; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < TB16; ++tb)
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj)
-                atomicAdd(&sAcc[(16 * ta + 4 * gq + jj) * TB + 16 * tb + r], acc[tl][ta][tb][jj]);
-        }
-        __syncthreads();
-        for (int i = t; i < TA * TB; i += 256) {
-          const int bl = i % TB, al = i / TB;
-          if (a0 + al < a.Ca_valid && b0 + bl < a.Cb_valid)
-            atomicAdd(a.dW + (long)(a0 + al) * a.sA + (long)(b0 + bl) * a.sB + a.tap_off[tap0 + tap_l], sAcc[i] * a.scale);
-        }
-        __syncthreads();
-      }
-    }
-  }
-}
-
-__global__ void wgrad_unpermute_kernel(UnpermuteArgs a) {
-  const long total = (long)a.ntaps * a.Ca * a.Cb;
-  const int ab = a.Ca * a.Cb;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int t = (int)(i / ab), rem = (int)(i - (long)t * ab);
-    const int aa = rem / a.Cb, bb = rem - aa * a.Cb;
-    // atomic: several taps may alias one destination (the pooled 1x1 heads share one weight across taps)
-    if (aa < a.Ca_valid && bb < a.Cb_valid) atomicAdd(a.dW + (long)aa * a.sA + (long)bb * a.sB + a.tap_off[t], a.scratch[i] * a.scale);
-  }
-}
-int launch_wgrad_unpermute(const UnpermuteArgs& a, hipStream_t s) {
-  const long total = (long)a.ntaps * a.Ca * a.Cb;
-  int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_unpermute_kernel, dim3(blocks), dim3(256), 0, s, a);
-  return check_launch("wgrad_unpermute");
-}
-
-int wgrad2_taps_per_block(int ta16, int tb16, int ntaps) {
-  int mt = 12 / (ta16 * tb16); if (mt < 1) mt = 1; if (mt > 4) mt = 4;
-  const int tg = ntaps >= 4 ? 4 * mt : mt;
-  return tg < ntaps ? tg : ntaps;
-}
-
-size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB) {
-  const size_t es = dtype_size(dt);
-  const size_t stage = (size_t)a.g.TP * TA * es + (size_t)a.g.segs * a.g.PR * a.g.PW * TB * es + 32 * 4 + 2048 * 4;
-  const size_t accb = (size_t)TA * TB * a.TG * 4;       // all-taps flush image (used only when it fits)
-  const size_t acc1 = (size_t)TA * TB * 4;              // per-tap flush image (always fits)
-  const size_t want = stage > acc1 ? stage : acc1;
-  return (accb > want && accb <= 48 * 1024) ? accb : want;
-}
-
-template <typename T>
-static int launch_wgrad2_t(Wgrad2Args a, int dt, dim3 grid, int ta16, int tb16, hipStream_t s) {
-  const size_t lds = wgrad2_lds_bytes(a, dt, ta16 * 16, tb16 * 16);
-  a.lds_bytes = (int)lds;
-  dim3 block(256);
-  const bool ts = a.ntaps >= 4;
-#define MMVAE_W2(A_, B_) do { if (ts) hipLaunchKernelGGL((wgrad2_kernel<T, A_, B_, true>), grid, block, lds, s, a); \
-                              else hipLaunchKernelGGL((wgrad2_kernel<T, A_, B_, false>), grid, block, lds, s, a); } while (0)
-  if (ta16 == 1 && tb16 == 1) MMVAE_W2(1, 1);
-  else if (ta16 == 1 && tb16 == 2) MMVAE_W2(1, 2);
-  else if (ta16 == 2 && tb16 == 1) MMVAE_W2(2, 1);
-  else if (ta16 == 2 && tb16 == 2) MMVAE_W2(2, 2);
-  else if (ta16 == 4 && tb16 == 2) MMVAE_W2(4, 2);
-  else if (ta16 == 2 && tb16 == 4) MMVAE_W2(2, 4);
-  else if (ta16 == 4 && tb16 == 4) MMVAE_W2(4, 4);
-  else if (ta16 == 4 && tb16 == 1) MMVAE_W2(4, 1);
-  else if (ta16 == 1 && tb16 == 4) MMVAE_W2(1, 4);
-  else { set_error("wgrad2: tile %dx%d unsupported", ta16, tb16); return MMVAE_ERR_UNSUPPORTED; }
-#undef MMVAE_W2
-  return check_launch("wgrad2");
-}
-
-int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s) {
-  dim3 grid(gx, tiles_ab, zg);
-  return dt == DT_F32 ? launch_wgrad2_t<float>(a, dt, grid, ta16, tb16, s) : launch_wgrad2_t<bf16_t>(a, dt, grid, ta16, tb16, s);
 }
 
 }  // namespace mmvae

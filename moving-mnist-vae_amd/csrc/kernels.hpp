@@ -45,9 +45,7 @@ struct WgradArgs {
   int N, Hp, Wp, Ca, Hg, Wg, Cb;
   int Cb_valid;            // b >= Cb_valid is computed but not written (0 -> Cb)
   int Ca_valid;            // likewise for a (0 -> Ca)
-  int P_planar, P_planes;  // 1: P is planar f32 [N][P_planes][Hp][Wp] staged as Ca=16 zero-padded channels (patch-tile kernel only)
-  int G_planar, G_planes;  // 2: G is planar T  [N][G_planes][Hg][Wg] staged as Cb=16 zero-padded channels
-  float* scratch;          // optional >= Ca*Cb*ntaps floats: large gradients are reduced into a coalesced [tap][a][b] image first
+  float* scratch;          // optional, kWgradScratchBytes: per-block partial images [part][tap][a][b], summed by wgrad_reduce_kernel
   int stride, pad, ksz;
   int sA, sB; int ntaps; int tap_off[25];
   float scale;
@@ -81,19 +79,18 @@ struct Wgrad2Args {
   const float* proG_scale; const float* proG_shift; int proG_relu;
   TileGeom g;
   int Ca, Cb, Cb_valid, Ca_valid, ksz, ntaps, TG;
-  int P_planar, P_planes, G_planar, G_planes;
   int sA, sB; int tap_off[25]; float scale;
-  int lds_bytes;           // dynamic LDS given to the block (set by the launcher)
-  int flush_per_tap;       // force the tap-by-tap flush (destination rows contiguous in b)
+  int partial;             // 1: dW is the partial-image scratch [gridDim.x][ntaps][Ca][Cb] (plain stores); 0: atomics into the weight layout
 };
 size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB);
+int wgrad2_patch_slots(const Wgrad2Args& a, int dt, int TB);
 int wgrad2_taps_per_block(int ta16, int tb16, int ntaps);
 int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s);
 size_t gather3_lds_bytes(const GatherArgs& a, int dt, int CT);
 int launch_gather3(int dt, int out_dt, const GatherArgs& a, int gx, hipStream_t s);
-// G[a*sA + b*sB + tap_off[t]] += scale * scratch[(t*Ca + a)*Cb + b]
-struct UnpermuteArgs { const float* scratch; float* dW; int Ca, Cb, ntaps, Ca_valid, Cb_valid, sA, sB; int tap_off[25]; float scale; };
-int launch_wgrad_unpermute(const UnpermuteArgs& a, hipStream_t s);
+struct WgradReduceArgs { const float* part; float* dW; int Ca, Cb, ntaps, nparts, Ca_valid, Cb_valid, sA, sB; int tap_off[25]; float scale; };
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s);
+constexpr size_t kWgradScratchBytes = 64u << 20;   // capacity of the partial-image scratch every wgrad caller provides
 bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
 // ---------------------------------------------------------------- weight packing

@@ -1,0 +1,40 @@
+// Device helpers shared by the patch-tile kernels (conv_tile.hip, conv_wgrad_*.hip).
+#pragma once
+#include "kernels.hpp"
+
+namespace mmvae {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ f32x4 mma_bf16(const Vec16& a, const Vec16& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma_f32v(const Vec16& a, const Vec16& b, f32x4 c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w[j]), __uint_as_float(b.w[j]), c, 0, 0, 0);
+  return c;
+}
+template <typename T> __device__ __forceinline__ f32x4 mma_vec(const Vec16& a, const Vec16& b, f32x4 c);
+template <> __device__ __forceinline__ f32x4 mma_vec<bf16_t>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_bf16(a, b, c); }
+template <> __device__ __forceinline__ f32x4 mma_vec<float>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_f32v(a, b, c); }
+
+__device__ __forceinline__ void tile_origin(const TileGeom& g, int tile, int seg, int& n, int& hq0) {
+  if (g.tiles_per_img > 0) {
+    n = tile / g.tiles_per_img;
+    hq0 = (tile - n * g.tiles_per_img) * g.qr;
+  } else {
+    n = tile * g.segs + seg;
+    hq0 = 0;
+  }
+}
+
+// patch pixel index (origin-relative, in pixels) of tile pixel p; p must be < segs*qr*Wq
+__device__ __forceinline__ int patch_index(const TileGeom& g, int p) {
+  const int per_seg = g.qr * g.Wq;
+  const int seg = p / per_seg, rem = p - seg * per_seg;
+  const int j = rem / g.Wq, wq = rem - j * g.Wq;
+  return (seg * g.PR + j * g.SI) * g.PW + wq * g.SI;
+}
+
+}  // namespace mmvae

@@ -135,7 +135,7 @@ const Plan& Net::plan(int N) {
   for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
   P.dy1 = take(maxact); P.dy2 = take(maxact); P.dys = take(maxact); P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
-  P.wscratch = take(std::max(max_w, 4L * cfg.z * 256) * 4);
+  P.wscratch = take((long)kWgradScratchBytes);
   P.bytes = (size_t)cur;
   plan_ = P;
   return plan_;
