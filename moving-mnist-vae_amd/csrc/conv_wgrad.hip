@@ -34,34 +34,61 @@ int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int
   return dt == DT_F32 ? launch_wgrad2_f32(a, grid, ta16, tb16, slots, s) : launch_wgrad2_bf16(a, grid, ta16, tb16, slots, s);
 }
 
-// dW[a*sA + b*sB + tap_off[t]] += scale * sum_{p < nparts} part[p][t][a][b];  grid = (wsize/256, part chunks)
+// dW[a*sA + b*sB + tap_off[t]] += scale * sum_{p < nparts} part[p][t][a][b]
+// Block = 256 consecutive elements x one chunk of parts: lane l of every wave owns the float4 column l, wave w sums the
+// parts w, w+4, ... of the chunk (8 loads in flight), the four waves combine through LDS.  grid = (wsize/256, chunks);
+// with one chunk (large gradients) the result is added with a plain read-modify-write, else with float atomics.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
+  __shared__ float4 sSum[4][64];
   const int ab = a.Ca * a.Cb;
-  const int wsize = a.ntaps * ab;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= wsize) return;
+  const int wsize = a.ntaps * ab;                 // multiple of 256 (Ca, Cb multiples of 16)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int per = (a.nparts + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * per, p1 = min(a.nparts, p0 + per);
-  const float* src = a.part + (long)p0 * wsize + i;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int p = p0;
-  for (; p + 4 <= p1; p += 4, src += 4L * wsize) {
-    s0 += src[0]; s1 += src[wsize]; s2 += src[2L * wsize]; s3 += src[3L * wsize];
+  const float* src = a.part + (long)blockIdx.x * 256 + lane * 4;
+  float4 s[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int p = p0 + wv;
+  for (; p + 12 < p1; p += 16) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)(p + 4 * k) * wsize);
+      s[k].x += v.x; s[k].y += v.y; s[k].z += v.z; s[k].w += v.w;
+    }
   }
-  for (; p < p1; ++p, src += wsize) s0 += src[0];
-  const float sum = (s0 + s1) + (s2 + s3);
+  for (; p < p1; p += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (long)p * wsize);
+    s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+  }
+  sSum[wv][lane] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                               (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  __syncthreads();
+  const float* f = reinterpret_cast<const float*>(sSum);
+  const int j = threadIdx.x;
+  const float sum = (f[j] + f[256 + j]) + (f[512 + j] + f[768 + j]);
+  const int i = blockIdx.x * 256 + j;
   const int t = i / ab, rem = i - t * ab;
   const int aa = rem / a.Cb, bb = rem - aa * a.Cb;
-  // atomic: part chunks add up, and several taps may alias one destination (the pooled 1x1 heads share one weight)
-  if (p1 > p0 && aa < a.Ca_valid && bb < a.Cb_valid) atomicAdd(a.dW + (long)aa * a.sA + (long)bb * a.sB + a.tap_off[t], sum * a.scale);
+  if (p1 > p0 && aa < a.Ca_valid && bb < a.Cb_valid) {
+    float* dst = a.dW + (long)aa * a.sA + (long)bb * a.sB + a.tap_off[t];
+    if (a.exclusive) *dst += sum * a.scale;
+    else atomicAdd(dst, sum * a.scale);
+  }
 }
 
-int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s) {
+int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s) {
   const int wsize = a.ntaps * a.Ca * a.Cb;
-  const int bx = (wsize + 255) / 256;
-  int gy = (2048 + bx - 1) / bx;                 // ~2048 blocks in flight
-  if (gy > a.nparts / 4) gy = a.nparts / 4;
+  if (wsize % 256) { set_error("wgrad_reduce: %d elements not a multiple of 256", wsize); return MMVAE_ERR_ARG; }
+  const int bx = wsize / 256;
+  int gy = (512 + bx - 1) / bx;                  // >= ~512 blocks ...
+  if (gy > a.nparts / 16) gy = a.nparts / 16;    // ... of >= 16 parts (4 per wave) each
   if (gy < 1) gy = 1;
+  // one chunk and distinct destinations (no two taps share a weight): plain read-modify-write
+  bool distinct = true;
+  for (int t = 0; t < a.ntaps && distinct; ++t)
+    for (int u = 0; u < t; ++u) if (a.tap_off[u] == a.tap_off[t]) { distinct = false; break; }
+  a.exclusive = (gy == 1 && distinct) ? 1 : 0;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, gy), dim3(256), 0, s, a);
   return check_launch("wgrad_reduce");
 }

@@ -88,8 +88,8 @@ int wgrad2_taps_per_block(int ta16, int tb16, int ntaps);
 int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s);
 size_t gather3_lds_bytes(const GatherArgs& a, int dt, int CT);
 int launch_gather3(int dt, int out_dt, const GatherArgs& a, int gx, hipStream_t s);
-struct WgradReduceArgs { const float* part; float* dW; int Ca, Cb, ntaps, nparts, Ca_valid, Cb_valid, sA, sB; int tap_off[25]; float scale; };
-int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t s);
+struct WgradReduceArgs { const float* part; float* dW; int Ca, Cb, ntaps, nparts, Ca_valid, Cb_valid, sA, sB; int tap_off[25]; float scale; int exclusive; };
+int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s);
 constexpr size_t kWgradScratchBytes = 64u << 20;   // capacity of the partial-image scratch every wgrad caller provides
 bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
