@@ -329,6 +329,57 @@ static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   return launch_gather2(dt, out_dt, b, gx, s);
 }
 
+// Pipelined all-phases patch kernel: eligible when the weights of every phase together with one patch fit LDS.
+// Returns >0 (stats rows) when it ran, 0 when not eligible, <0 on error.
+static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
+  static const int enabled = [] { const char* e = getenv("MMVAE_PATCH"); return e ? atoi(e) : 1; }();
+  if (!enabled || a.Cout > 64 || a.Cin > 256) return 0;
+  const int VE = dt == DT_F32 ? 4 : 8;
+  if (a.x_planar && (a.Cin > 16 || a.x_planes > a.Cin || a.pro_scale)) return 0;
+  if (a.y_planes && (a.Cout != 16 || a.y_planes > 16)) return 0;
+  const int cin_vecs = a.Cin / VE;
+  if (!a.x_planar && (256 % cin_vecs) != 0) return 0;
+  PatchArgs b; memset(&b, 0, sizeof(b));
+  b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
+  b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate;
+  b.Cin = a.Cin; b.Cout = a.Cout; b.Ho = a.Ho; b.Wo = a.Wo; b.SO = a.SO; b.nphase = a.nphase;
+  b.x_planar = a.x_planar; b.x_planes = a.x_planes; b.y_planes = a.y_planes;
+  int ct16 = (a.Cout + 15) / 16; if (ct16 == 3) ct16 = 4;
+  const int CT = ct16 * 16;
+  int dh0 = 0, dh1 = 0, dw0 = 0, dw1 = 0, Hq = 0, Wq = 0;
+  bool first = true;
+  for (int p = 0; p < a.nphase; ++p) {
+    const Phase& ph = a.phases[p];
+    if (ph.ntaps <= 0) return 0;
+    for (int t = 0; t < ph.ntaps; ++t) {
+      const Tap tp = a.taps[ph.tap0 + t];
+      if (first) { dh0 = dh1 = tp.dh; dw0 = dw1 = tp.dw; first = false; }
+      dh0 = tp.dh < dh0 ? tp.dh : dh0; dh1 = tp.dh > dh1 ? tp.dh : dh1;
+      dw0 = tp.dw < dw0 ? tp.dw : dw0; dw1 = tp.dw > dw1 ? tp.dw : dw1;
+    }
+    Hq = ph.Hq > Hq ? ph.Hq : Hq; Wq = ph.Wq > Wq ? ph.Wq : Wq;
+    PatchPhase& q = b.phases[p];
+    q.ph = ph.ph; q.pw = ph.pw; q.Hq = ph.Hq; q.Wq = ph.Wq; q.ntaps = ph.ntaps; q.tap0 = ph.tap0; q.w_off = ph.w_off;
+    const int kvp = (ph.ntaps * cin_vecs + 3) & ~3;
+    q.w_vec0 = b.w_vecs; q.koff0 = b.koff_total;
+    b.w_vecs += CT * (kvp + 1); b.koff_total += kvp;
+  }
+  if ((size_t)b.w_vecs * 16 > 40 * 1024) return 0;
+  for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
+  if (!make_tile_geom(b.g, a.N, Hq, Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1, 128, 1)) return 0;
+  const size_t lds = patch_conv_lds_bytes(b, dt);
+  const int slots = patch_conv_slots(b, dt);
+  if (lds > kV2MaxLds || slots > 12) return 0;
+  int occ = (int)((160 * 1024) / lds);
+  const int occ_regs = slots <= 4 ? (ct16 == 1 ? 4 : (ct16 == 2 ? 3 : 2)) : 2;
+  if (occ > occ_regs) occ = occ_regs;
+  if (occ < 1) occ = 1;
+  int gx = 256 * occ;
+  if (gx > b.g.ntiles) gx = b.g.ntiles;
+  if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
+  return launch_patch_conv(dt, out_dt, b, gx, s);
+}
+
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
   if (a.Cin % VE != 0 || a.Cout % 4 != 0 || a.nphase < 1 || a.nphase > kMaxPhases) {
@@ -347,6 +398,10 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   }
   if (ntap > kMaxTaps) { set_error("gather_gemm: %d taps > %d", ntap, kMaxTaps); return MMVAE_ERR_UNSUPPORTED; }
   if (max_tiles <= 0) return 1;
+  if (!conv_force_v1()) {
+    const int rcp = try_patch(dt, out_dt, a, s);
+    if (rcp != 0) return rcp;
+  }
   {
     // thin layers: barrier-free streaming kernel (weights in LDS, pixels straight from global memory)
     static const int g3_maxk = [] { const char* e = getenv("MMVAE_GATHER3_MAXK"); return e ? atoi(e) : 160; }();

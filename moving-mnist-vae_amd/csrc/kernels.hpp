@@ -91,6 +91,21 @@ int launch_gather3(int dt, int out_dt, const GatherArgs& a, int gx, hipStream_t 
 struct WgradReduceArgs { const float* part; float* dW; int Ca, Cb, ntaps, nparts, Ca_valid, Cb_valid, sA, sB; int tap_off[25]; float scale; int exclusive; };
 int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s);
 constexpr size_t kWgradScratchBytes = 64u << 20;   // capacity of the partial-image scratch every wgrad caller provides
+// ---- pipelined all-phases patch kernel (conv_patch.hip)
+struct PatchPhase { int ph, pw, Hq, Wq, ntaps, tap0; long w_off; int w_vec0, koff0; };
+struct PatchArgs {
+  const void* x; const void* w; void* y;
+  const float* pro_scale; const float* pro_shift; int pro_relu;
+  const float* bias; float* stats; int accumulate;
+  int Cin, Cout, Ho, Wo, SO;
+  TileGeom g;                  // one geometry for all phases: q-grid = max over phases, patch = union of the tap spans
+  int nphase; PatchPhase phases[kMaxPhases]; Tap taps[kMaxTaps];
+  int w_vecs, koff_total;      // LDS carve: weight vec16s of all phases, k-offset ints of all phases
+  int x_planar, x_planes, y_planes;
+};
+size_t patch_conv_lds_bytes(const PatchArgs& a, int dt);
+int patch_conv_slots(const PatchArgs& a, int dt);
+int launch_patch_conv(int dt, int out_dt, const PatchArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
 bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
 // ---------------------------------------------------------------- weight packing
