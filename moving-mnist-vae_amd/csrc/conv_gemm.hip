@@ -334,6 +334,7 @@ static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
 static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   static const int enabled = [] { const char* e = getenv("MMVAE_PATCH"); return e ? atoi(e) : 1; }();
   if (!enabled || a.Cout > 64 || a.Cin > 256) return 0;
+  if ((long)a.N * a.Ho * a.Wo * (a.y_planes ? a.y_planes : a.Cout) >= (1L << 30)) return 0;     // 32-bit output offsets
   const int VE = dt == DT_F32 ? 4 : 8;
   if (a.x_planar && (a.Cin > 16 || a.x_planes > a.Cin || a.pro_scale)) return 0;
   if (a.y_planes && (a.Cout != 16 || a.y_planes > 16)) return 0;
@@ -366,15 +367,36 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   }
   if ((size_t)b.w_vecs * 16 > 40 * 1024) return 0;
   for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
-  if (!make_tile_geom(b.g, a.N, Hq, Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1, 128, 1)) return 0;
-  const size_t lds = patch_conv_lds_bytes(b, dt);
-  const int slots = patch_conv_slots(b, dt);
-  if (lds > kV2MaxLds || slots > 12) return 0;
+  // tile size: 128 q-pixels, or 256 / 512 (whole rows, power-of-two width >= 16) for the 16- and 32-channel layers:
+  // bigger tiles amortise barriers, tile decode and the patch halo
+  static const int sub_env = [] { const char* e = getenv("MMVAE_PATCH_SUB"); return e ? atoi(e) : 0; }();
+  int max_sub = ct16 == 1 ? (a.x_planar ? 4 : 2) : 1;       // measured per layer class (tools/sweep_env.sh MMVAE_PATCH_SUB)
+  if (sub_env > 0) { const int inst = ct16 == 1 ? 4 : (ct16 == 2 ? 2 : 1); max_sub = sub_env < inst ? sub_env : inst; }
+  const bool pow2w = Wq >= 16 && (Wq & (Wq - 1)) == 0;
+  size_t lds = 0;
+  int slots = 0;
+  bool ok = false;
+  TileGeom g1;
+  const bool have1 = make_tile_geom(g1, a.N, Hq, Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1, 128, 1);
+  if (!have1) return 0;
+  for (int sub = max_sub; sub >= 1 && !ok; sub >>= 1) {
+    if (sub > 1 && (!pow2w || Hq * Wq < 128 * sub)) continue;
+    if (!make_tile_geom(b.g, a.N, Hq, Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1, 128, sub)) continue;
+    if (sub > 1 && (b.g.tiles_per_img == 0 || b.g.qr * Wq != 128 * sub)) continue;
+    if (sub > 1 && b.g.ntiles < 1024 && g1.ntiles >= 1024) continue;       // keep >= 1024 tiles when the problem has them
+    lds = patch_conv_lds_bytes(b, dt);
+    slots = patch_conv_slots(b, dt);
+    ok = lds <= (sub > 1 ? 40 * 1024 : kV2MaxLds) && slots <= 12;
+    if (ok) { b.npt = 2 * sub; b.wq_shift = 0; while ((1 << b.wq_shift) < Wq) ++b.wq_shift; }
+  }
+  if (!ok) return 0;
   int occ = (int)((160 * 1024) / lds);
   const int occ_regs = slots <= 4 ? (ct16 == 1 ? 4 : (ct16 == 2 ? 3 : 2)) : 2;
   if (occ > occ_regs) occ = occ_regs;
   if (occ < 1) occ = 1;
   int gx = 256 * occ;
+  if (b.npt >= 4 && slots <= 4 && occ > occ_regs - 1 && occ > 1) occ = occ_regs - 1;
+  gx = 256 * occ;
   if (gx > b.g.ntiles) gx = b.g.ntiles;
   if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
   return launch_patch_conv(dt, out_dt, b, gx, s);

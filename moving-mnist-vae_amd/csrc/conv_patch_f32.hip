@@ -1,0 +1,3 @@
+// f32 instances of the pipelined patch-tile conv kernel (see conv_patch.inc).
+#define PATCH_TU 0
+#include "conv_patch.inc"

@@ -93,4 +93,29 @@ int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s) {
   return check_launch("wgrad_reduce");
 }
 
+// ---------------------------------------------------------------- patch_conv host side
+int launch_patch_conv_f32(const PatchArgs& a, int gx, hipStream_t s);
+int launch_patch_conv_bf16(const PatchArgs& a, int gx, hipStream_t s);
+int launch_patch_conv_bf16_f32(const PatchArgs& a, int gx, hipStream_t s);
+
+size_t patch_conv_lds_bytes(const PatchArgs& a, int dt) {
+  const int VE = dt == DT_F32 ? 4 : 8;
+  const int cin_vecs = a.Cin / VE;
+  int ct16 = (a.Cout + 15) / 16; if (ct16 == 3) ct16 = 4;
+  return (size_t)a.w_vecs * 16 + (size_t)a.g.segs * a.g.PR * a.g.PW * cin_vecs * 16 + (size_t)a.koff_total * 4 + (size_t)8 * ct16 * 16 * 4;
+}
+
+int patch_conv_slots(const PatchArgs& a, int dt) {
+  const int VE = dt == DT_F32 ? 4 : 8;
+  const int npatch = a.g.segs * a.g.PR * a.g.PW;
+  const int per_round = a.x_planar ? 256 : 256 / (a.Cin / VE);
+  return (npatch + per_round - 1) / per_round;
+}
+
+int launch_patch_conv(int dt, int out_dt, const PatchArgs& a, int gx, hipStream_t s) {
+  if (dt == DT_F32) return launch_patch_conv_f32(a, gx, s);
+  if (out_dt == DT_F32) return launch_patch_conv_bf16_f32(a, gx, s);
+  return launch_patch_conv_bf16(a, gx, s);
+}
+
 }  // namespace mmvae

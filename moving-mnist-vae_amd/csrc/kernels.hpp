@@ -102,6 +102,7 @@ struct PatchArgs {
   int nphase; PatchPhase phases[kMaxPhases]; Tap taps[kMaxTaps];
   int w_vecs, koff_total;      // LDS carve: weight vec16s of all phases, k-offset ints of all phases
   int x_planar, x_planes, y_planes;
+  int npt, wq_shift;           // 16-pixel column tiles per wave (2, 4, 8); log2(Wq) when npt > 2
 };
 size_t patch_conv_lds_bytes(const PatchArgs& a, int dt);
 int patch_conv_slots(const PatchArgs& a, int dt);
