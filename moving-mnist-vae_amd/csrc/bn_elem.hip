@@ -421,19 +421,47 @@ int launch_affine_nchw(const float* raw, const float* scale, const float* shift,
   hipLaunchKernelGGL(affine_nchw_kernel, dim3(blocks), dim3(256), 0, s, raw, scale, shift, out, total, C, HW);
   return check_launch("affine_nchw");
 }
-__global__ void bn_bwd_apply_nchw_kernel(const float* __restrict__ dout, const float* __restrict__ y, const float* __restrict__ A,
-                                         const float* __restrict__ B, const float* __restrict__ Cc, float* __restrict__ dy,
-                                         long total, int C, int HW) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)((i / HW) % C);
-    dy[i] = A[c] * dout[i] + B[c] * y[i] + Cc[c];
+// dy = A[c]*dout + B[c]*y + C[c] on NCHW f32 planes; optionally dbias[c] += sum(dy) (the bias gradient of the conv that
+// produced y).  Block = whole planes (n, c).
+__global__ __launch_bounds__(256) void bn_bwd_apply_nchw_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                                const float* __restrict__ A, const float* __restrict__ B,
+                                                                const float* __restrict__ Cc, float* __restrict__ dy, int planes, int C,
+                                                                int HW, float* __restrict__ dbias) {
+  __shared__ float sAcc[64];
+  if (threadIdx.x < 64) sAcc[threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+    const int c = p % C;
+    const float ca = A[c], cb = B[c], cc = Cc[c];
+    const long base = (long)p * HW;
+    float s = 0.f;
+    if ((HW & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+        const float4 d = *reinterpret_cast<const float4*>(dout + base + i);
+        const float4 v = *reinterpret_cast<const float4*>(y + base + i);
+        float4 o;
+        o.x = ca * d.x + cb * v.x + cc; o.y = ca * d.y + cb * v.y + cc; o.z = ca * d.z + cb * v.z + cc; o.w = ca * d.w + cb * v.w + cc;
+        *reinterpret_cast<float4*>(dy + base + i) = o;
+        s += (o.x + o.y) + (o.z + o.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        const float o = ca * dout[base + i] + cb * y[base + i] + cc;
+        dy[base + i] = o;
+        s += o;
+      }
+    }
+    if (dbias) { s = wave_sum(s); if ((threadIdx.x & 63) == 0) atomicAdd(&sAcc[c], s); }
   }
+  __syncthreads();
+  if (dbias && threadIdx.x < C) atomicAdd(dbias + threadIdx.x, sAcc[threadIdx.x]);
 }
 int launch_bn_bwd_apply_nchw(const float* dout, const float* y, const float* A, const float* B, const float* Cc, float* dy,
-                             int N, int C, int HW, hipStream_t s) {
-  const long total = (long)N * C * HW;
-  const int blocks = elem_blocks(total / 4 + 1, 256);
-  hipLaunchKernelGGL(bn_bwd_apply_nchw_kernel, dim3(blocks), dim3(256), 0, s, dout, y, A, B, Cc, dy, total, C, HW);
+                             int N, int C, int HW, hipStream_t s, float* dbias) {
+  if (C > 64) { set_error("bn_bwd_apply_nchw: C=%d > 64", C); return MMVAE_ERR_UNSUPPORTED; }
+  const int planes = N * C;
+  const int blocks = planes < 4096 ? planes : 4096;
+  hipLaunchKernelGGL(bn_bwd_apply_nchw_kernel, dim3(blocks), dim3(256), 0, s, dout, y, A, B, Cc, dy, planes, C, HW, dbias);
   return check_launch("bn_bwd_apply_nchw");
 }
 

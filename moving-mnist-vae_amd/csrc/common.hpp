@@ -27,6 +27,14 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   return __builtin_bit_cast(uint16_t, h);
 }
 
+// two floats -> one dword of two bf16 (round-to-nearest-even): a single v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kVec = 4;          // elements per 16 B
@@ -61,7 +69,7 @@ template <> struct Elem<bf16_t> {
     Vec16 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      v.w[i] = (uint32_t)f32_to_bf16_bits(f[2 * i]) | ((uint32_t)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+      v.w[i] = pack2_bf16(f[2 * i], f[2 * i + 1]);
     return v;
   }
 };

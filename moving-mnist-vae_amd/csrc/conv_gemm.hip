@@ -50,8 +50,8 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
     f[2] += __uint_as_float(e.y << 16); f[3] += __uint_as_float(e.y & 0xffff0000u);
   }
   uint2 o;
-  o.x = (uint32_t)f32_to_bf16_bits(f[0]) | ((uint32_t)f32_to_bf16_bits(f[1]) << 16);
-  o.y = (uint32_t)f32_to_bf16_bits(f[2]) | ((uint32_t)f32_to_bf16_bits(f[3]) << 16);
+  o.x = pack2_bf16(f[0], f[1]);
+  o.y = pack2_bf16(f[2], f[3]);
   *reinterpret_cast<uint2*>(p) = o;
 }
 
@@ -249,6 +249,12 @@ static int launch_gather_t(GatherArgs& a, int gx, hipStream_t s) {
   return rc ? rc : gx * a.nphase;
 }
 
+int conv_xcd_walk() {
+  // not cached: developer sweeps (tools/sweep_env.sh) flip it between processes only, but reading it is cheap
+  const char* e = getenv("MMVAE_XCD");
+  return (e && e[0] == '0') ? 0 : 1;
+}
+
 bool conv_force_v1() {
   static const int v = [] { const char* e = getenv("MMVAE_CONV_V1"); return (e && e[0] == '1') ? 1 : 0; }();
   return v != 0;
@@ -335,6 +341,7 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   static const int enabled = [] { const char* e = getenv("MMVAE_PATCH"); return e ? atoi(e) : 1; }();
   if (!enabled || a.Cout > 64 || a.Cin > 256) return 0;
   if ((long)a.N * a.Ho * a.Wo * (a.y_planes ? a.y_planes : a.Cout) >= (1L << 30)) return 0;     // 32-bit output offsets
+  if (!a.x_planar && (long)a.N * a.Hi * a.Wi * a.Cin * (long)dtype_size(dt) >= (1L << 31)) return 0;   // buffer-load range
   const int VE = dt == DT_F32 ? 4 : 8;
   if (a.x_planar && (a.Cin > 16 || a.x_planes > a.Cin || a.pro_scale)) return 0;
   if (a.y_planes && (a.Cout != 16 || a.y_planes > 16)) return 0;
@@ -370,24 +377,46 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   // tile size: 128 q-pixels, or 256 / 512 (whole rows, power-of-two width >= 16) for the 16- and 32-channel layers:
   // bigger tiles amortise barriers, tile decode and the patch halo
   static const int sub_env = [] { const char* e = getenv("MMVAE_PATCH_SUB"); return e ? atoi(e) : 0; }();
+  static const int uni_env = [] { const char* e = getenv("MMVAE_PATCH_UNI"); return e ? atoi(e) : 1; }();
   int max_sub = ct16 == 1 ? (a.x_planar ? 4 : 2) : 1;       // measured per layer class (tools/sweep_env.sh MMVAE_PATCH_SUB)
   if (sub_env > 0) { const int inst = ct16 == 1 ? 4 : (ct16 == 2 ? 2 : 1); max_sub = sub_env < inst ? sub_env : inst; }
+  // uniform geometry (whole rows, power-of-two width >= 16, every (ph, pw) phase present and full-size): LDS epilogue
   const bool pow2w = Wq >= 16 && (Wq & (Wq - 1)) == 0;
+  bool uni_ok = uni_env && pow2w && Hq * Wq >= 128 && a.nphase == a.SO * a.SO && a.SO <= 2 && (!a.y_planes || a.SO == 1);
+  for (int i = 0; i < 4; ++i) b.phase_of[i] = -1;
+  for (int p = 0; p < a.nphase && uni_ok; ++p) {
+    const Phase& ph = a.phases[p];
+    if (ph.Hq != Hq || ph.Wq != Wq || ph.ph < 0 || ph.ph >= a.SO || ph.pw < 0 || ph.pw >= a.SO || b.phase_of[ph.ph * a.SO + ph.pw] >= 0) uni_ok = false;
+    else b.phase_of[ph.ph * a.SO + ph.pw] = p;
+  }
+  if (uni_ok && (Hq * a.SO != a.Ho || Wq * a.SO != a.Wo || (!a.y_planes && a.Cout % 16 != 0))) uni_ok = false;
+  const size_t out_es = out_dt == DT_F32 ? 4 : dtype_size(dt);
   size_t lds = 0;
   int slots = 0;
   bool ok = false;
   TileGeom g1;
   const bool have1 = make_tile_geom(g1, a.N, Hq, Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1, 128, 1);
   if (!have1) return 0;
-  for (int sub = max_sub; sub >= 1 && !ok; sub >>= 1) {
-    if (sub > 1 && (!pow2w || Hq * Wq < 128 * sub)) continue;
+  for (int sub = uni_ok ? max_sub : 1; sub >= 1 && !ok; sub >>= 1) {
+    if (sub > 1 && Hq * Wq < 128 * sub) continue;
     if (!make_tile_geom(b.g, a.N, Hq, Wq, a.Hi, a.Wi, a.SI, dh0, dw0, dh1 - dh0 + 1, dw1 - dw0 + 1, 128, sub)) continue;
     if (sub > 1 && (b.g.tiles_per_img == 0 || b.g.qr * Wq != 128 * sub)) continue;
     if (sub > 1 && b.g.ntiles < 1024 && g1.ntiles >= 1024) continue;       // keep >= 1024 tiles when the problem has them
+    b.npt = 2 * sub;
+    b.uni = (uni_ok && b.g.tiles_per_img > 0 && b.g.qr * Wq == 128 * sub) ? 1 : 0;
+    if (sub > 1 && !b.uni) continue;
+    // staging buffer of one wave: NCHW planes, or channel-quad planes [npt][SO][ct16][4] of (16 q x 4 channels + 16 B skew)
+    b.out_wave_bytes = !b.uni ? 0 : (int)(a.y_planes ? (size_t)a.y_planes * b.npt * 16 * 4 : (size_t)b.npt * a.SO * ct16 * 4 * (16 * 4 * out_es + 16));
+    b.out_wave_bytes = (b.out_wave_bytes + 15) & ~15;
     lds = patch_conv_lds_bytes(b, dt);
     slots = patch_conv_slots(b, dt);
-    ok = lds <= (sub > 1 ? 40 * 1024 : kV2MaxLds) && slots <= 12;
-    if (ok) { b.npt = 2 * sub; b.wq_shift = 0; while ((1 << b.wq_shift) < Wq) ++b.wq_shift; }
+    ok = lds <= (sub > 1 ? 48 * 1024 : kV2MaxLds) && slots <= 12;
+    if (!ok && b.uni && sub == 1) {          // the staging buffers did not fit: general epilogue
+      b.uni = 0; b.out_wave_bytes = 0;
+      lds = patch_conv_lds_bytes(b, dt);
+      ok = lds <= kV2MaxLds && slots <= 12;
+    }
+    if (ok) { b.wq_shift = 0; while ((1 << b.wq_shift) < Wq) ++b.wq_shift; }
   }
   if (!ok) return 0;
   int occ = (int)((160 * 1024) / lds);
@@ -399,6 +428,10 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   gx = 256 * occ;
   if (gx > b.g.ntiles) gx = b.g.ntiles;
   if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
+  if (gx >= 8) gx &= ~7;
+  b.xcd_walk = conv_xcd_walk();
+  { const char* e = getenv("MMVAE_DBG"); b.dbg = e ? atoi(e) : 0; }
+  b.x_bytes = a.x_planar ? 0u : (unsigned)((long)a.N * a.Hi * a.Wi * a.Cin * (long)dtype_size(dt));
   return launch_patch_conv(dt, out_dt, b, gx, s);
 }
 
@@ -609,7 +642,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
 // Returns 1 when the v2 kernel ran, 0 when not eligible, <0 on error.
 static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
-  if (conv_force_v1() || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
+  if ((conv_force_v1() && !a.P_planar) || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
+  if (a.P_planar && (a.Ca != 16 || a.P_planes > 16 || a.proP_scale)) return 0;
   auto pick = [](int c) { return c >= 64 ? 64 : c; };
   const int TA = pick(a.Ca), TB = pick(a.Cb);
   if (!(TA == 16 || TA == 32 || TA == 64) || !(TB == 16 || TB == 32 || TB == 64)) return 0;
@@ -629,8 +663,24 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
     fits = lds <= kV2MaxLds && wgrad2_patch_slots(b, dt, TB) <= 16;
   }
   if (!fits) return 0;
+  // big tiles (16x16 channel tile, >= 4 taps, P width a power of two >= 32): fewer, larger tiles amortise the per-tile
+  // latency of the thin 64x64 / 32x32 layers
+  static const int big_env = [] { const char* e = getenv("MMVAE_WGRAD_BIG"); return e ? atoi(e) : 1; }();   // measured: no gain (off by default)
+  if (ta16 == 1 && tb16 == 1 && a.ntaps >= 4 && a.Wp >= 32 && (a.Wp & (a.Wp - 1)) == 0 && b.g.TP == 128 && big_env > 1) {
+    for (int sub = big_env > 4 ? 4 : big_env; sub >= 2; sub >>= 1) {
+      Wgrad2Args c = b;
+      if (!make_tile_geom(c.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, 128, sub)) continue;
+      if (c.g.tiles_per_img == 0 || c.g.qr * a.Wp != 128 * sub || a.Hp % c.g.qr != 0) continue;
+      if (c.g.ntiles < 1024 && b.g.ntiles >= 1024) continue;
+      const size_t l2 = wgrad2_lds_bytes(c, dt, TA, TB);
+      if (l2 > 48 * 1024 || wgrad2_patch_slots(c, dt, TB) > 16) continue;
+      b = c; lds = l2; b.big = 1;
+      while ((1 << b.wq_shift) < a.Wp) ++b.wq_shift;
+      break;
+    }
+  }
   b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.Ca_valid = a.Ca_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
-  b.sA = a.sA; b.sB = a.sB; b.scale = a.scale;
+  b.sA = a.sA; b.sB = a.sB; b.scale = a.scale; b.P_planar = a.P_planar; b.P_planes = a.P_planes;
   for (int t = 0; t < 25; ++t) b.tap_off[t] = a.tap_off[t];
   const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
   const int zg = (a.ntaps + b.TG - 1) / b.TG;
@@ -655,6 +705,8 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
     if (gx > cap) gx = cap;
   }
   if (gx > b.g.ntiles) gx = b.g.ntiles;
+  if (gx >= 8) gx &= ~7L;
+  b.xcd_walk = conv_xcd_walk();
   if (partial) { b.dW = a.scratch; b.partial = 1; }
   const int rc = launch_wgrad2(dt, b, (int)gx, tiles_ab, zg, ta16, tb16, s);
   if (rc < 0) return rc;
@@ -682,6 +734,7 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   {
     const int rc2 = try_wgrad2(dt, a, s);
     if (rc2 != 0) return rc2 < 0 ? rc2 : MMVAE_OK;
+    if (a.P_planar) { set_error("wgrad: planar P needs the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }
   }
   const int TA = a.Ca >= 64 ? 64 : ((a.Ca + 15) / 16) * 16;
   const int TB = a.Cb >= 64 ? 64 : ((a.Cb + 15) / 16) * 16;

@@ -118,8 +118,8 @@ template <> __device__ __forceinline__ void store4v<bf16_t>(bf16_t* p, const flo
     f[2] += __uint_as_float(e.y << 16); f[3] += __uint_as_float(e.y & 0xffff0000u);
   }
   uint2 o;
-  o.x = (uint32_t)f32_to_bf16_bits(f[0]) | ((uint32_t)f32_to_bf16_bits(f[1]) << 16);
-  o.y = (uint32_t)f32_to_bf16_bits(f[2]) | ((uint32_t)f32_to_bf16_bits(f[3]) << 16);
+  o.x = pack2_bf16(f[0], f[1]);
+  o.y = pack2_bf16(f[2], f[3]);
   *reinterpret_cast<uint2*>(p) = o;
 }
 

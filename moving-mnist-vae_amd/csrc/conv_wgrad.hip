@@ -102,7 +102,8 @@ size_t patch_conv_lds_bytes(const PatchArgs& a, int dt) {
   const int VE = dt == DT_F32 ? 4 : 8;
   const int cin_vecs = a.Cin / VE;
   int ct16 = (a.Cout + 15) / 16; if (ct16 == 3) ct16 = 4;
-  return (size_t)a.w_vecs * 16 + (size_t)a.g.segs * a.g.PR * a.g.PW * cin_vecs * 16 + (size_t)a.koff_total * 4 + (size_t)8 * ct16 * 16 * 4;
+  return (size_t)a.w_vecs * 16 + (size_t)a.g.segs * a.g.PR * a.g.PW * cin_vecs * 16 + (size_t)a.koff_total * 4 + (size_t)8 * ct16 * 16 * 4 +
+         (a.uni ? (size_t)4 * a.out_wave_bytes : 0);
 }
 
 int patch_conv_slots(const PatchArgs& a, int dt) {

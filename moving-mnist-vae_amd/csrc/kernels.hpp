@@ -45,6 +45,7 @@ struct WgradArgs {
   int N, Hp, Wp, Ca, Hg, Wg, Cb;
   int Cb_valid;            // b >= Cb_valid is computed but not written (0 -> Cb)
   int Ca_valid;            // likewise for a (0 -> Ca)
+  int P_planar, P_planes;  // 1: P is planar f32 [N][P_planes][Hp][Wp] (patch-tile kernel only; Ca = 16, Ca_valid = P_planes)
   float* scratch;          // optional, kWgradScratchBytes: per-block partial images [part][tap][a][b], summed by wgrad_reduce_kernel
   int stride, pad, ksz;
   int sA, sB; int ntaps; int tap_off[25];
@@ -80,6 +81,9 @@ struct Wgrad2Args {
   TileGeom g;
   int Ca, Cb, Cb_valid, Ca_valid, ksz, ntaps, TG;
   int sA, sB; int tap_off[25]; float scale;
+  int P_planar, P_planes;  // 1: P is planar f32 [N][P_planes][Hq][Wq] staged as Ca = 16 zero-padded channels
+  int xcd_walk;            // XCD-aware tile order (tile_common.hpp)
+  int big, wq_shift;       // big tiles (256 / 512 P-pixels, see conv_wgrad.inc); log2(Wq)
   int partial;             // 1: dW is the partial-image scratch [gridDim.x][ntaps][Ca][Cb] (plain stores); 0: atomics into the weight layout
 };
 size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB);
@@ -103,11 +107,17 @@ struct PatchArgs {
   int w_vecs, koff_total;      // LDS carve: weight vec16s of all phases, k-offset ints of all phases
   int x_planar, x_planes, y_planes;
   int npt, wq_shift;           // 16-pixel column tiles per wave (2, 4, 8); log2(Wq) when npt > 2
+  int xcd_walk;                // XCD-aware tile order (tile_common.hpp)
+  int uni, out_wave_bytes;     // uniform geometry: LDS-staged epilogue, bytes of one wave's staging buffer
+  int phase_of[4];             // uni: phase index of output sub-position (ph, pw) = [ph*SO + pw]
+  int dbg;                     // developer switches (MMVAE_DBG): 1 skip loads, 2 skip LDS commit, 4 skip MFMA+epilogue, 8 skip stores
+  unsigned x_bytes;            // size of x in bytes (< 2^31): buffer-load range for the NHWC staging
 };
 size_t patch_conv_lds_bytes(const PatchArgs& a, int dt);
 int patch_conv_slots(const PatchArgs& a, int dt);
 int launch_patch_conv(int dt, int out_dt, const PatchArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
-bool conv_force_v1();   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
+bool conv_force_v1();
+int conv_xcd_walk();      // MMVAE_XCD (default 1): XCD-aware tile order in the persistent patch-tile kernels   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
 // ---------------------------------------------------------------- weight packing
 // dst[(col*ntaps + t)*K + k] = T(scale * src[col*s_col + k*s_k + tap_off[t]])
@@ -178,7 +188,7 @@ int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* 
 int launch_affine_nchw(const float* raw, const float* scale, const float* shift, float* out, int N, int C, int HW, hipStream_t s);
 int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s);
 int launch_bn_bwd_apply_nchw(const float* dout, const float* y, const float* A, const float* B, const float* Cc, float* dy,
-                             int N, int C, int HW, hipStream_t s);
+                             int N, int C, int HW, hipStream_t s, float* dbias = nullptr);
 
 // ---------------------------------------------------------------- latent / loss
 // enc = mu + exp(0.5*logvar)*eps (f32 and T copies); kl_partial: -0.5*sum(lv - exp(lv) - mu^2 + 1) (one float, atomically added)

@@ -37,4 +37,17 @@ __device__ __forceinline__ int patch_index(const TileGeom& g, int p) {
   return (seg * g.PR + j * g.SI) * g.PW + wq * g.SI;
 }
 
+// Blocks are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8; every XCD has its own L2).  Give each
+// XCD one contiguous eighth of the tiles and let blocks of neighbouring rank walk neighbouring tiles, so that the halo
+// rows two adjacent tiles share are served by one L2 instead of being fetched into two.  Falls back to the plain
+// grid-stride walk when the grid is not a multiple of 8.
+struct TileWalk { int first, step, end; };        // tiles first, first + step, ... < end
+__device__ __forceinline__ TileWalk xcd_tile_walk(int ntiles, int enable) {
+  const int B = gridDim.x, b = blockIdx.x;
+  if (!enable || (B & 7) != 0) return TileWalk{b, B, ntiles};
+  const int per = (ntiles + 7) >> 3;
+  const int lo = (b & 7) * per;
+  return TileWalk{lo + (b >> 3), B >> 3, min(ntiles, lo + per)};
+}
+
 }  // namespace mmvae

@@ -525,10 +525,20 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   int np = launch_bn_bwd_reduce_nchw(d_recon, r_raw, N, cfg.out_ch, HW, part, s);
   MM_TRY(np);
   MM_TRY(bn_backward_coefs(bn_out, params, grads, base, np, 1, 0, (double)N * HW, s));
-  MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
-  {
-    // direct kernel: dW[oc][ci][kh][kw] and d(bias) (measured faster than the padded-P MFMA path)
-    MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, grads + tail_bias, N, Sd, Sd, cfg.out_ch, s));
+  // (the tail conv's bias gradient, sum of d_raw per output channel, comes out of the same pass)
+  MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s,
+                                  grads + tail_bias));
+  static const bool tail_wgrad_direct = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_DIRECT"); return e && e[0] == '1'; }();
+  if (tail_wgrad_direct) {
+    MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, nullptr, N, Sd, Sd, cfg.out_ch, s));
+  } else {
+    // dW[oc][ci][kh][kw]: P = d_raw (planar f32, out_ch planes staged as 16 zero-padded channels), G = the last up-block's output
+    WgradArgs a; std::memset(&a, 0, sizeof(a));
+    a.P = d_raw; a.P_planar = 1; a.P_planes = cfg.out_ch; a.G = base + dec[nup - 1].out; a.dW = grads + tail.off; a.scratch = wscratch_;
+    a.N = N; a.Hp = Sd; a.Wp = Sd; a.Ca = 16; a.Ca_valid = cfg.out_ch; a.Hg = Sd; a.Wg = Sd; a.Cb = 16; a.Cb_valid = 16;
+    a.stride = 1; a.pad = 1; a.ksz = 3; a.sA = 16 * 9; a.sB = 9; a.ntaps = 9; a.scale = 1.f;
+    for (int t = 0; t < 9; ++t) a.tap_off[t] = t;
+    MM_TRY(launch_wgrad(dt(), a, s));
   }
   int cur = 0;
   static const bool tail_direct = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
