@@ -109,7 +109,7 @@ def dominant_kernel_roofline(M, device, N, reps=20):
     alg = x.numel() * 2 + y.numel() * 2 + w.numel() * 2
     ach = alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "gather3_kernel<bf16,bf16,1,2> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16->16 k4 s2, 4 stride-phases in one launch, + weight pack)",
+            "kernel": "patch_conv_kernel<bf16,bf16,1,4,false,4,true> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16->16 k4 s2, 32x32 -> 64x64; all 4 stride-phases from one LDS patch, + weight pack)",
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
 
 

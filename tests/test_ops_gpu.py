@@ -36,6 +36,8 @@ CONFIGS = [
     (16, 16, 4, 2, 1, 1, 16, 2), (16, 16, 4, 2, 1, 1, 32, 1),
     (32, 128, 2, 2, 0, 1, 1, 37), (128, 128, 2, 2, 0, 1, 1, 300),                               # decoder stem (z -> 128)
     (16, 16, 1, 1, 0, 0, 64, 40), (16, 16, 4, 2, 1, 1, 32, 36),                                  # > 1024 pixel tiles
+    (16, 16, 3, 1, 1, 0, 64, 2), (32, 32, 4, 2, 1, 1, 16, 4), (16, 32, 3, 2, 1, 0, 64, 2),       # 256/512-pixel row tiles, LDS-staged epilogue
+    (32, 16, 3, 1, 1, 0, 32, 3), (16, 16, 4, 2, 1, 0, 64, 2),
 ]
 
 
