@@ -1,0 +1,3 @@
+// f32 instances of the deep-layer implicit-GEMM conv kernel (see conv_deep.inc).
+#define DEEP_TU 0
+#include "conv_deep.inc"

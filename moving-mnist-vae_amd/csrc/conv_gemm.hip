@@ -435,6 +435,51 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   return launch_patch_conv(dt, out_dt, b, gx, s);
 }
 
+// Deep-layer implicit GEMM (conv_deep.inc): channel-heavy layers on small feature maps, whole images per tile.
+// Returns >0 (stats rows) when it ran, 0 when not eligible, <0 on error.
+static int try_deep(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
+  static const int enabled = [] { const char* e = getenv("MMVAE_DEEP"); return e ? atoi(e) : 1; }();
+  if (!enabled || a.x_planar || a.y_planes) return 0;
+  const int VE = dt == DT_F32 ? 4 : 8;
+  if (a.Cin < 64 || a.Cin % (8 * VE) != 0 || a.Cout < 64 || a.Cout % 64 != 0) return 0;
+  const int cin_vecs = a.Cin / VE;
+  if (512 % cin_vecs != 0) return 0;
+  if ((long)a.N * a.Ho * a.Wo * a.Cout >= (1L << 32)) return 0;
+  DeepArgs b; memset(&b, 0, sizeof(b));
+  b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
+  b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate;
+  b.N = a.N; b.Hi = a.Hi; b.Wi = a.Wi; b.Cin = a.Cin; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = a.SI; b.SO = a.SO;
+  b.nphase = a.nphase;
+  for (int p = 0; p < a.nphase; ++p) {
+    const Phase& ph = a.phases[p];
+    if (ph.ntaps <= 0) return 0;
+    b.phases[p] = DeepPhase{ph.ph, ph.pw, ph.Hq, ph.Wq, ph.ntaps, ph.tap0, ph.w_off};
+    b.Hq = ph.Hq > b.Hq ? ph.Hq : b.Hq; b.Wq = ph.Wq > b.Wq ? ph.Wq : b.Wq;
+    b.ntaps_all = ph.tap0 + ph.ntaps > b.ntaps_all ? ph.tap0 + ph.ntaps : b.ntaps_all;
+  }
+  if (b.ntaps_all > kMaxTaps) return 0;
+  for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
+  b.ct16 = a.Cout >= 128 ? 8 : 4;
+  const int gy = (a.Cout + b.ct16 * 16 - 1) / (b.ct16 * 16);
+  const int wp = 8 / (b.ct16 / 4);
+  const int hw = b.Hq * b.Wq;
+  bool ok = false;
+  for (int npt = b.ct16 == 8 ? 4 : 2; npt >= 1 && !ok; npt >>= 1) {
+    const int TPX = wp * npt * 16;
+    if (hw > TPX) break;
+    b.npt = npt; b.ipt = TPX / hw;
+    if (b.ipt > a.N) b.ipt = a.N;
+    if (b.ipt * a.Hi * a.Wi >= 65535) continue;
+    b.ntiles = (a.N + b.ipt - 1) / b.ipt;
+    if (npt > 1 && (long)b.ntiles * gy < 256 && a.N * hw > 256 * (TPX / 2)) continue;     // keep every CU busy when the problem allows
+    ok = deep_conv_lds_bytes(b, dt) <= 150 * 1024;
+  }
+  if (!ok) return 0;
+  int gx = b.ntiles < 512 ? b.ntiles : 512;
+  if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
+  return launch_deep_conv(dt, out_dt, b, gx, s);
+}
+
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
   if (a.Cin % VE != 0 || a.Cout % 4 != 0 || a.nphase < 1 || a.nphase > kMaxPhases) {
@@ -456,6 +501,8 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   if (!conv_force_v1()) {
     const int rcp = try_patch(dt, out_dt, a, s);
     if (rcp != 0) return rcp;
+    const int rcd = try_deep(dt, out_dt, a, s);
+    if (rcd != 0) return rcd;
   }
   {
     // thin layers: barrier-free streaming kernel (weights in LDS, pixels straight from global memory)

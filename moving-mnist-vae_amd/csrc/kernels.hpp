@@ -116,6 +116,20 @@ struct PatchArgs {
 size_t patch_conv_lds_bytes(const PatchArgs& a, int dt);
 int patch_conv_slots(const PatchArgs& a, int dt);
 int launch_patch_conv(int dt, int out_dt, const PatchArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
+// ---- deep-layer implicit GEMM (conv_deep.inc): resident unpadded patch + streamed weights, 512 threads
+struct DeepPhase { int ph, pw, Hq, Wq, ntaps, tap0; long w_off; };
+struct DeepArgs {
+  const void* x; const void* w; void* y;
+  const float* pro_scale; const float* pro_shift; int pro_relu;
+  const float* bias; float* stats; int accumulate;
+  int N, Hi, Wi, Cin, Ho, Wo, Cout, SI, SO;
+  int Hq, Wq;                  // q-grid of a tile image (max over phases)
+  int nphase; DeepPhase phases[kMaxPhases]; Tap taps[kMaxTaps]; int ntaps_all;
+  int ipt, ntiles;             // whole images per tile, tiles
+  int ct16, npt;               // cout tile / 16 (4 or 8), 16-pixel column tiles per wave
+};
+size_t deep_conv_lds_bytes(const DeepArgs& a, int dt);
+int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
 bool conv_force_v1();
 int conv_xcd_walk();      // MMVAE_XCD (default 1): XCD-aware tile order in the persistent patch-tile kernels   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
