@@ -80,12 +80,12 @@ int launch_chan_stats_nhwc(int dt, const void* y, long npix, int C, float* parti
 // ---------------------------------------------------------------- channel statistics (NCHW f32)
 // planes = N*C; block handles planes blockIdx.x, +gridDim.x, ...; partials [gridDim.x][NR][C]
 template <int NR>
-__global__ void plane_reduce_nchw_kernel(const float* __restrict__ a, const float* __restrict__ b, int N, int C, int HW,
-                                         float* __restrict__ partials) {
-  // NR=2, b==null: (sum a, sum a^2);  NR=2, b!=null: (sum a, sum a*b)
+__global__ __launch_bounds__(256) void plane_reduce_nchw_kernel(const float* __restrict__ a, const float* __restrict__ b, int N, int C, int HW,
+                                                                 float* __restrict__ partials) {
+  // NR=2, b==null: (sum a, sum a^2);  NR=2, b!=null: (sum a, sum a*b).  No barrier per plane: every wave reduces its
+  // share of a plane and adds it to the block's per-channel LDS accumulators.
   extern __shared__ float sm[];
   float* sAcc = sm;             // [NR][C]
-  float* sRed = sm + NR * C;    // [NR * nwaves]
   for (int i = threadIdx.x; i < NR * C; i += blockDim.x) sAcc[i] = 0.f;
   __syncthreads();
   const int planes = N * C;
@@ -93,20 +93,30 @@ __global__ void plane_reduce_nchw_kernel(const float* __restrict__ a, const floa
     const int c = p % C;
     const float* pa = a + (long)p * HW;
     const float* pb = b ? b + (long)p * HW : nullptr;
-    float v[2] = {0.f, 0.f};
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-      const float x = pa[i];
-      v[0] += x;
-      v[1] += pb ? x * pb[i] : x * x;
+    float v0 = 0.f, v1 = 0.f;
+    if ((HW & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < HW; i += 4 * blockDim.x) {
+        const float4 x = *reinterpret_cast<const float4*>(pa + i);
+        float4 y = x;
+        if (pb) y = *reinterpret_cast<const float4*>(pb + i);
+        v0 += (x.x + x.y) + (x.z + x.w);
+        v1 += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float x = pa[i];
+        v0 += x;
+        v1 += pb ? x * pb[i] : x * x;
+      }
     }
-    block_sum<2>(v, sRed);
-    if (threadIdx.x == 0) { sAcc[c] += v[0]; sAcc[C + c] += v[1]; }
-    __syncthreads();
+    v0 = wave_sum(v0); v1 = wave_sum(v1);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sAcc[c], v0); atomicAdd(&sAcc[C + c], v1); }
   }
+  __syncthreads();
   for (int i = threadIdx.x; i < NR * C; i += blockDim.x) partials[(long)blockIdx.x * NR * C + i] = sAcc[i];
 }
 
-static int nchw_parts(int N, int C) { int p = N * C; return p > 512 ? 512 : (p < 1 ? 1 : p); }
+static int nchw_parts(int N, int C) { int p = N * C; return p > 1024 ? 1024 : (p < 1 ? 1 : p); }
 
 int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials, hipStream_t s) {
   const int blocks = nchw_parts(N, C);

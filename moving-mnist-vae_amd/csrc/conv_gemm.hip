@@ -689,8 +689,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 
 // Returns 1 when the v2 kernel ran, 0 when not eligible, <0 on error.
 static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
-  if ((conv_force_v1() && !a.P_planar) || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
+  if ((conv_force_v1() && !a.P_planar && !a.G_planar) || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
   if (a.P_planar && (a.Ca != 16 || a.P_planes > 16 || a.proP_scale)) return 0;
+  if (a.G_planar && (a.Cb != 16 || a.Ca != 32 || a.proG_scale || a.ntaps < 4)) return 0;
   auto pick = [](int c) { return c >= 64 ? 64 : c; };
   const int TA = pick(a.Ca), TB = pick(a.Cb);
   if (!(TA == 16 || TA == 32 || TA == 64) || !(TB == 16 || TB == 32 || TB == 64)) return 0;
@@ -727,7 +728,7 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
     }
   }
   b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.Ca_valid = a.Ca_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
-  b.sA = a.sA; b.sB = a.sB; b.scale = a.scale; b.P_planar = a.P_planar; b.P_planes = a.P_planes;
+  b.sA = a.sA; b.sB = a.sB; b.scale = a.scale; b.P_planar = a.P_planar; b.P_planes = a.P_planes; b.G_planar = a.G_planar;
   for (int t = 0; t < 25; ++t) b.tap_off[t] = a.tap_off[t];
   const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
   const int zg = (a.ntaps + b.TG - 1) / b.TG;
@@ -781,7 +782,7 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   {
     const int rc2 = try_wgrad2(dt, a, s);
     if (rc2 != 0) return rc2 < 0 ? rc2 : MMVAE_OK;
-    if (a.P_planar) { set_error("wgrad: planar P needs the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }
+    if (a.P_planar || a.G_planar) { set_error("wgrad: planar operands need the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }
   }
   const int TA = a.Ca >= 64 ? 64 : ((a.Ca + 15) / 16) * 16;
   const int TB = a.Cb >= 64 ? 64 : ((a.Cb + 15) / 16) * 16;

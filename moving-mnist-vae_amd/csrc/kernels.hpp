@@ -46,6 +46,7 @@ struct WgradArgs {
   int Cb_valid;            // b >= Cb_valid is computed but not written (0 -> Cb)
   int Ca_valid;            // likewise for a (0 -> Ca)
   int P_planar, P_planes;  // 1: P is planar f32 [N][P_planes][Hp][Wp] (patch-tile kernel only; Ca = 16, Ca_valid = P_planes)
+  int G_planar;            // 1: G is planar T [N][1][Hg][Wg] (patch-tile kernel only; Cb = 16, Cb_valid = 1)
   float* scratch;          // optional, kWgradScratchBytes: per-block partial images [part][tap][a][b], summed by wgrad_reduce_kernel
   int stride, pad, ksz;
   int sA, sB; int ntaps; int tap_off[25];
@@ -82,6 +83,7 @@ struct Wgrad2Args {
   int Ca, Cb, Cb_valid, Ca_valid, ksz, ntaps, TG;
   int sA, sB; int tap_off[25]; float scale;
   int P_planar, P_planes;  // 1: P is planar f32 [N][P_planes][Hq][Wq] staged as Ca = 16 zero-padded channels
+  int G_planar;            // 1: G is planar T [N][1][Hi][Wi] (the 1-channel image) staged as Cb = 16 zero-padded channels
   int xcd_walk;            // XCD-aware tile order (tile_common.hpp)
   int big, wq_shift;       // big tiles (256 / 512 P-pixels, see conv_wgrad.inc); log2(Wq)
   int partial;             // 1: dW is the partial-image scratch [gridDim.x][ntaps][Ca][Cb] (plain stores); 0: atomics into the weight layout

@@ -428,13 +428,22 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(bn_backward_coefs(bn0, params, grads, base, np, 1, 0, (double)npix, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, bnf(bn0, base, 4),
                                bnf(bn0, base, 5), bnf(bn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 32, s));
-    // im2col of the 1-channel image (25 taps padded to 32 columns) + the MFMA weight-gradient kernel (measured faster than
-    // padding the image patch to 16 channels in LDS)
-    MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, s));
+    // measured: im2col + 1x1 weight gradient 0.39 ms, planar-G patch-tile path 0.42 ms (MMVAE_STEM_PLANAR=1)
+    static const bool stem_im2col = [] { const char* e = getenv("MMVAE_STEM_PLANAR"); return !(e && e[0] == '1'); }();
     WgradArgs a; std::memset(&a, 0, sizeof(a));
-    a.P = base + P.dy1; a.G = base + P.col; a.dW = grads + stem.off;
-    a.N = N; a.Hp = H1; a.Wp = W1; a.Ca = 32; a.Hg = H1; a.Wg = W1; a.Cb = 32; a.Cb_valid = 25;
-    a.stride = 1; a.pad = 0; a.ksz = 1; a.sA = 25; a.sB = 1; a.ntaps = 1; a.scale = 1.f;
+    a.P = base + P.dy1; a.dW = grads + stem.off; a.scratch = wscratch_;
+    a.N = N; a.Hp = H1; a.Wp = W1; a.Ca = 32; a.scale = 1.f;
+    if (stem_im2col) {
+      // im2col of the 1-channel image (25 taps padded to 32 columns) + the MFMA weight-gradient kernel as a 1x1 conv
+      MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, s));
+      a.G = base + P.col; a.Hg = H1; a.Wg = W1; a.Cb = 32; a.Cb_valid = 25;
+      a.stride = 1; a.pad = 0; a.ksz = 1; a.sA = 25; a.sB = 1; a.ntaps = 1;
+    } else {
+      // dW[co][0][kh][kw]: P = dy (32 channels), G = the planar 1-channel image staged as 16 zero-padded channels in LDS
+      a.G = base + P.x_t; a.G_planar = 1; a.Hg = cfg.S; a.Wg = cfg.S; a.Cb = 16; a.Cb_valid = 1;
+      a.stride = 2; a.pad = 2; a.ksz = 5; a.sA = 25; a.sB = 25; a.ntaps = 25;
+      for (int t = 0; t < 25; ++t) a.tap_off[t] = t;
+    }
     MM_TRY(launch_wgrad(dt(), a, s));
   }
   return MMVAE_OK;
