@@ -83,10 +83,12 @@ template <int NR>
 __global__ __launch_bounds__(256) void plane_reduce_nchw_kernel(const float* __restrict__ a, const float* __restrict__ b, int N, int C, int HW,
                                                                  float* __restrict__ partials) {
   // NR=2, b==null: (sum a, sum a^2);  NR=2, b!=null: (sum a, sum a*b).  No barrier per plane: every wave reduces its
-  // share of a plane and adds it to the block's per-channel LDS accumulators.
+  // share of a plane into its OWN per-channel LDS accumulators (single writer, fixed order -> bit-reproducible sums);
+  // the four waves are combined once at the end.
   extern __shared__ float sm[];
-  float* sAcc = sm;             // [NR][C]
-  for (int i = threadIdx.x; i < NR * C; i += blockDim.x) sAcc[i] = 0.f;
+  float* sAcc = sm;             // [4 waves][NR][C]
+  const int wid = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * NR * C; i += blockDim.x) sAcc[i] = 0.f;
   __syncthreads();
   const int planes = N * C;
   for (int p = blockIdx.x; p < planes; p += gridDim.x) {
@@ -110,17 +112,18 @@ __global__ __launch_bounds__(256) void plane_reduce_nchw_kernel(const float* __r
       }
     }
     v0 = wave_sum(v0); v1 = wave_sum(v1);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&sAcc[c], v0); atomicAdd(&sAcc[C + c], v1); }
+    if ((threadIdx.x & 63) == 0) { sAcc[wid * NR * C + c] += v0; sAcc[wid * NR * C + C + c] += v1; }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NR * C; i += blockDim.x) partials[(long)blockIdx.x * NR * C + i] = sAcc[i];
+  for (int i = threadIdx.x; i < NR * C; i += blockDim.x)
+    partials[(long)blockIdx.x * NR * C + i] = (sAcc[i] + sAcc[NR * C + i]) + (sAcc[2 * NR * C + i] + sAcc[3 * NR * C + i]);
 }
 
 static int nchw_parts(int N, int C) { int p = N * C; return p > 1024 ? 1024 : (p < 1 ? 1 : p); }
 
 int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials, hipStream_t s) {
   const int blocks = nchw_parts(N, C);
-  const size_t sm = (2 * C + 2 * 4) * sizeof(float);
+  const size_t sm = (size_t)4 * 2 * C * sizeof(float);
   hipLaunchKernelGGL((plane_reduce_nchw_kernel<2>), dim3(blocks), dim3(256), sm, s, y, (const float*)nullptr, N, C, HW, partials);
   int rc = check_launch("chan_stats_nchw");
   return rc ? rc : blocks;
@@ -128,7 +131,7 @@ int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials
 
 int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s) {
   const int blocks = nchw_parts(N, C);
-  const size_t sm = (2 * C + 2 * 4) * sizeof(float);
+  const size_t sm = (size_t)4 * 2 * C * sizeof(float);
   hipLaunchKernelGGL((plane_reduce_nchw_kernel<2>), dim3(blocks), dim3(256), sm, s, dout, y, N, C, HW, partials);
   int rc = check_launch("bn_bwd_reduce_nchw");
   return rc ? rc : blocks;

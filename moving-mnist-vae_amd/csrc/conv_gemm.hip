@@ -755,6 +755,7 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   if (gx > b.g.ntiles) gx = b.g.ntiles;
   if (gx >= 8) gx &= ~7L;
   b.xcd_walk = conv_xcd_walk();
+  { const char* e = getenv("MMVAE_DBG"); b.dbg = e ? atoi(e) : 0; }
   if (partial) { b.dW = a.scratch; b.partial = 1; }
   const int rc = launch_wgrad2(dt, b, (int)gx, tiles_ab, zg, ta16, tb16, s);
   if (rc < 0) return rc;

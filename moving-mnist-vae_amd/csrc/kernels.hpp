@@ -85,6 +85,7 @@ struct Wgrad2Args {
   int P_planar, P_planes;  // 1: P is planar f32 [N][P_planes][Hq][Wq] staged as Ca = 16 zero-padded channels
   int G_planar;            // 1: G is planar T [N][1][Hi][Wi] (the 1-channel image) staged as Cb = 16 zero-padded channels
   int xcd_walk;            // XCD-aware tile order (tile_common.hpp)
+  int dbg;                 // developer switches (MMVAE_DBG): 1 skip loads, 2 skip LDS commit, 4 skip MFMA phase
   int big, wq_shift;       // big tiles (256 / 512 P-pixels, see conv_wgrad.inc); log2(Wq)
   int partial;             // 1: dW is the partial-image scratch [gridDim.x][ntaps][Ca][Cb] (plain stores); 0: atomics into the weight layout
 };

@@ -164,6 +164,31 @@ int Net::run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws
   return op_run_up(dt(), geom(w), base + plan_.packed + w.packU * (long)esz(), N, S, Hs, Ws, L, Hl, Wl, pro_s, pro_b, relu, stats,
                    accumulate, s);
 }
+hipStream_t Net::wgrad_stream(hipStream_t s) {
+  if (side_state_ == 0) {
+    const char* e = getenv("MMVAE_SIDE_STREAM");
+    side_state_ = (e && e[0] == '0') ? -1 : 1;
+    if (side_state_ == 1) {
+      bool ok = hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) == hipSuccess;
+      for (int i = 0; i < 64 && ok; ++i) ok = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) { (void)hipGetLastError(); side_state_ = -1; }
+    }
+  }
+  return side_state_ == 1 ? side_ : s;
+}
+int Net::side_fork(hipStream_t s) {
+  if (wgrad_stream(s) == s) return MMVAE_OK;
+  hipEvent_t e = ev_[evi_++ & 63];     // 64 > forks + joins of one backward pass: no event is re-recorded while a wait on it may be pending
+  if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(side_, e, 0) != hipSuccess) { set_error("side stream fork failed"); return MMVAE_ERR_HIP; }
+  return MMVAE_OK;
+}
+int Net::side_join(hipStream_t s) {
+  if (wgrad_stream(s) == s) return MMVAE_OK;
+  hipEvent_t e = ev_[evi_++ & 63];     // 64 > forks + joins of one backward pass: no event is re-recorded while a wait on it may be pending
+  if (hipEventRecord(e, side_) != hipSuccess || hipStreamWaitEvent(s, e, 0) != hipSuccess) { set_error("side stream join failed"); return MMVAE_ERR_HIP; }
+  return MMVAE_OK;
+}
+
 int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
                    const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s) {
   return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_);
@@ -374,7 +399,8 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     a.N = N; a.Hp = 1; a.Wp = 1; a.Ca = Ch; a.Hg = Hf; a.Wg = Wf; a.Cb = 256; a.Cb_valid = 256;
     a.stride = Hf; a.pad = 0; a.ksz = Hf; a.sA = 256; a.sB = 1; a.ntaps = nt; a.scale = 1.0f / nt;
     a.scratch = wscratch_;
-    MM_TRY(launch_wgrad(dt(), a, s));
+    MM_TRY(side_fork(s));
+    MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
     pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / nt;
@@ -393,6 +419,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     const void* xin = i == 0 ? base + P.y0 : base + enc[i - 1].out;
     const float* xs = i == 0 ? bnf(bn0, base, 2) : nullptr;
     const float* xb = i == 0 ? bnf(bn0, base, 3) : nullptr;
+    if (i != 3) MM_TRY(side_join(s));          // the previous block's weight gradients still read dy1 / dy2 / dys
     // join backward: g = d_out * [out > 0] feeds bn2 (y2) and the shortcut BN (ys)
     int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npix, B.C, part, s,
                                   bnf(B.bs, base, 2), bnf(B.bs, base, 3));
@@ -403,8 +430,11 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
                                bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
                                base + P.dys, npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
+    hipStream_t wsm = wgrad_stream(s);
+    MM_TRY(side_fork(s));
     MM_TRY(run_wgrad(B.c2, N, base + P.dy2, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
-                     bnf(B.b1, base, 3), grads, s));
+                     bnf(B.b1, base, 3), grads, wsm));
+    MM_TRY(run_wgrad(B.cs, N, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(run_up(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
     // bn1 + relu backward
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
@@ -414,13 +444,14 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
                                bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix,
                                B.C, s));
     // conv1 (3x3 s2) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
-    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
-    MM_TRY(run_wgrad(B.cs, N, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
+    MM_TRY(side_fork(s));
+    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
     MM_TRY(run_up(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     cur ^= 1;
   }
-  // ---- stem: bn0 + relu backward, then the 5x5 weight gradient (image patch padded to 16 channels in LDS)
+  // ---- stem: bn0 + relu backward, then the 5x5 weight gradient
+  MM_TRY(side_join(s));            // block 0's conv1 weight gradient still reads dy1
   {
     const long npix = (long)N * H1 * W1;
     int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, nullptr, npix, 32, part, s);
@@ -430,12 +461,14 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
                                bnf(bn0, base, 5), bnf(bn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 32, s));
     // measured: im2col + 1x1 weight gradient 0.39 ms, planar-G patch-tile path 0.42 ms (MMVAE_STEM_PLANAR=1)
     static const bool stem_im2col = [] { const char* e = getenv("MMVAE_STEM_PLANAR"); return !(e && e[0] == '1'); }();
+    MM_TRY(side_fork(s));
+    hipStream_t wsm = wgrad_stream(s);
     WgradArgs a; std::memset(&a, 0, sizeof(a));
     a.P = base + P.dy1; a.dW = grads + stem.off; a.scratch = wscratch_;
     a.N = N; a.Hp = H1; a.Wp = W1; a.Ca = 32; a.scale = 1.f;
     if (stem_im2col) {
       // im2col of the 1-channel image (25 taps padded to 32 columns) + the MFMA weight-gradient kernel as a 1x1 conv
-      MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, s));
+      MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wsm));
       a.G = base + P.col; a.Hg = H1; a.Wg = W1; a.Cb = 32; a.Cb_valid = 25;
       a.stride = 1; a.pad = 0; a.ksz = 1; a.sA = 25; a.sB = 1; a.ntaps = 1;
     } else {
@@ -444,7 +477,8 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
       a.stride = 2; a.pad = 2; a.ksz = 5; a.sA = 25; a.sB = 25; a.ntaps = 25;
       for (int t = 0; t < 25; ++t) a.tap_off[t] = t;
     }
-    MM_TRY(launch_wgrad(dt(), a, s));
+    MM_TRY(launch_wgrad(dt(), a, wsm));
+    MM_TRY(side_join(s));
   }
   return MMVAE_OK;
 }
@@ -547,7 +581,8 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     a.N = N; a.Hp = Sd; a.Wp = Sd; a.Ca = 16; a.Ca_valid = cfg.out_ch; a.Hg = Sd; a.Wg = Sd; a.Cb = 16; a.Cb_valid = 16;
     a.stride = 1; a.pad = 1; a.ksz = 3; a.sA = 16 * 9; a.sB = 9; a.ntaps = 9; a.scale = 1.f;
     for (int t = 0; t < 9; ++t) a.tap_off[t] = t;
-    MM_TRY(launch_wgrad(dt(), a, s));
+    MM_TRY(side_fork(s));
+    MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
   }
   int cur = 0;
   static const bool tail_direct = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
@@ -572,6 +607,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     const void* xin = i == 0 ? base + P.y0d : base + dec[i - 1].out;
     const float* xs = i == 0 ? bnf(dbn0, base, 2) : nullptr;
     const float* xb = i == 0 ? bnf(dbn0, base, 3) : nullptr;
+    if (i != nup - 1) MM_TRY(side_join(s));    // the previous block's weight gradients still read dy1 / dy2 / dys
     np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
                               bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);
@@ -581,8 +617,11 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
                                base + P.dys, npo, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
+    hipStream_t wsm = wgrad_stream(s);
+    MM_TRY(side_fork(s));
     MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2, B.Hout, B.Wout, nullptr,
-                     nullptr, grads, s));
+                     nullptr, grads, wsm));
+    MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
     MM_TRY(run_down(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
     MM_TRY(np);
@@ -591,14 +630,15 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npi,
                                B.C, s));
     // conv1 (1x1): wgrad(P = dy1, G = xin); upsample (ConvT): wgrad(P = xin, G = dys)
-    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, s));
-    MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, grads, s));
+    MM_TRY(side_fork(s));
+    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     // d_xin = dgrad(conv1)(dy1) + dgrad(upsample)(dys)
     MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
     MM_TRY(run_down(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, dt(), s));
     cur ^= 1;
   }
   // ---- decoder stem
+  MM_TRY(side_join(s));            // up-block 0's conv1 weight gradient still reads dy1
   {
     const long npix = (long)N * 4;
     np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(dbn0, base, 2), bnf(dbn0, base, 3), base + P.y0d, nullptr, npix, 128, part, s);
@@ -606,11 +646,13 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(bn_backward_coefs(dbn0, params, grads, base, np, 1, 0, (double)npix, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(dbn0, base, 2), bnf(dbn0, base, 3), base + P.y0d, bnf(dbn0, base, 4),
                                bnf(dbn0, base, 5), bnf(dbn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 128, s));
-    MM_TRY(run_wgrad(dstem, N, base + P.enc_t, 1, 1, nullptr, nullptr, base + P.dy1, 2, 2, nullptr, nullptr, grads, s));
+    MM_TRY(side_fork(s));
+    MM_TRY(run_wgrad(dstem, N, base + P.enc_t, 1, 1, nullptr, nullptr, base + P.dy1, 2, 2, nullptr, nullptr, grads, wgrad_stream(s)));
     if (d_enc) {
       MM_TRY(run_down(dstem, base, N, base + P.dy1, 2, 2, base + P.dh, 1, 1, nullptr, nullptr, 0, nullptr, 0, dt(), s));
       MM_TRY(launch_convert(dt(), DT_F32, base + P.dh, d_enc, (long)N * cfg.z, s));
     }
+    MM_TRY(side_join(s));
   }
   return MMVAE_OK;
 }

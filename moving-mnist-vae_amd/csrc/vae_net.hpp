@@ -74,6 +74,12 @@ class Net {
  private:
   Plan plan_;
   float* wscratch_ = nullptr;
+  // weight gradients run on a side stream, concurrently with the dgrad / BatchNorm-backward chain of the same block
+  // (the deep-layer kernels are latency-bound and leave most CUs idle); MMVAE_SIDE_STREAM=0 disables it
+  hipStream_t side_ = nullptr; hipEvent_t ev_[64] = {}; int evi_ = 0; int side_state_ = 0;   // 0 unknown, 1 on, -1 off
+  hipStream_t wgrad_stream(hipStream_t s);      // stream the weight gradients are enqueued on
+  int side_fork(hipStream_t s);                 // side stream waits for everything enqueued on s so far
+  int side_join(hipStream_t s);                 // s waits for everything enqueued on the side stream so far
   int dt() const { return cfg.dtype; }
   size_t esz() const { return dtype_size(cfg.dtype); }
   ConvW add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack);

@@ -95,7 +95,10 @@ def test_fused_adam_resume(pkg, oracle, tmp_path):
     assert oc._t == ob._t == 2 and torch.equal(oc._m, ob._m) and torch.equal(oc._v, ob._v) and torch.equal(c._flat, b._flat)
     run(c, oc, [2])
     torch.cuda.synchronize()
-    # decoder.conv2.bias feeds a BatchNorm: its gradient is analytically zero, Adam turns the rounding noise into +-lr
+    # decoder.conv2.bias feeds a BatchNorm: its gradient is analytically zero, Adam turns the rounding noise into +-lr.
+    # The same happens to single elements with a (near-)zero gradient (float-atomic summation order differs from run to
+    # run), so the comparison is a relative L2 norm per tensor, not an element-wise maximum.
     pa = dict(a.named_parameters())
-    err = max((p - pa[k]).abs().max().item() for k, p in c.named_parameters() if k != "decoder.conv2.bias")
-    assert err < 1e-4, err
+    errs = {k: ((p - pa[k]).norm() / pa[k].norm()).item() for k, p in c.named_parameters() if k != "decoder.conv2.bias"}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 1e-3, (worst, errs[worst])
