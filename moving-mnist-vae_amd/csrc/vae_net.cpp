@@ -131,7 +131,7 @@ const Plan& Net::plan(int N) {
   P.col = act((long)N * H1 * W1 * 32);
   P.packed = take(n_packed * e);
   P.bnws = take(n_bnws * 4);
-  P.partials = take(4096L * 3 * 256 * 4);
+  P.partials = take(2 * kPartialFloats * 4);       // second half: the shortcut branch running on the side stream
   for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
   P.dy1 = take(maxact); P.dy2 = take(maxact); P.dys = take(maxact); P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
@@ -194,9 +194,10 @@ int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const f
   return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_);
 }
 
-int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s) {
+int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s,
+                  long part_off) {
   BnFinalizeArgs a;
-  a.partials = reinterpret_cast<const float*>(base + plan_.partials); a.nparts = nparts; a.C = bn.C; a.count = count;
+  a.partials = reinterpret_cast<const float*>(base + plan_.partials) + part_off; a.nparts = nparts; a.C = bn.C; a.count = count;
   a.gamma = params + bn.g_off; a.beta = params + bn.b_off;
   a.running_mean = bnbuf ? bnbuf + bn.rm_off : nullptr; a.running_var = bnbuf ? bnbuf + bn.rv_off : nullptr;
   a.nbt = nbt ? nbt + bn.nbt_idx : nullptr;
@@ -347,16 +348,21 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   for (int i = 0; i < 4; ++i) {
     Block& B = enc[i];
     const double cnt = (double)N * B.Hout * B.Wout;
-    int np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
+    // shortcut branch (conv + its BatchNorm) on the side stream, concurrently with conv1 -> bn1 -> conv2 -> bn2
+    static const bool side_fwd = [] { const char* e = getenv("MMVAE_SIDE_FWD"); return !(e && e[0] == '0'); }();
+    if (side_fwd) MM_TRY(side_fork(s));
+    hipStream_t ss = side_fwd ? wgrad_stream(s) : s;
+    int np = run_down(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, dt(), ss);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
+    np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b1, params, bnbuf, base, s));
-    np = run_down(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
-    MM_TRY(np);
-    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.bs, params, bnbuf, base, s));
     np = run_down(B.c2, base, N, base + B.y1, B.Hout, B.Wout, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
                   stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
+    if (side_fwd) MM_TRY(side_join(s));
     MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2),
                            bnf(B.bs, base, 3), base + B.out, (long)N * B.Hout * B.Wout, B.C, s));
     xin = base + B.out; xs = xb = nullptr;
@@ -504,16 +510,21 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   const float* xb = bnf(dbn0, base, 3);
   for (int i = 0; i < nup; ++i) {
     Block& B = dec[i];
+    const double cnt = (double)N * B.Hout * B.Wout;
+    // upsample (shortcut) branch on the side stream, concurrently with conv1 -> bn1 -> conv2 -> bn2
+    static const bool side_fwd = [] { const char* e = getenv("MMVAE_SIDE_FWD"); return !(e && e[0] == '0'); }();
+    if (side_fwd) MM_TRY(side_fork(s));
+    hipStream_t ss = side_fwd ? wgrad_stream(s) : s;
+    np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, ss);
+    MM_TRY(np);
+    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
     np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hin, B.Win, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, (double)N * B.Hin * B.Win, s) : bn_eval(B.b1, params, bnbuf, base, s));
-    const double cnt = (double)N * B.Hout * B.Wout;
     np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
-    np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats, 0, s);
-    MM_TRY(np);
-    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.bs, params, bnbuf, base, s));
+    if (side_fwd) MM_TRY(side_join(s));
     MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2),
                            bnf(B.bs, base, 3), base + B.out, (long)N * B.Hout * B.Wout, B.C, s));
     xin = base + B.out; xs = xb = nullptr;
