@@ -5,8 +5,9 @@ on synthetic 20x64x64 Moving-MNIST clips (BASELINE.json configs[1]: 256 clips = 
   python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of this repo's ``train`` loop body (main.py:371-399 restated) over one batch that is already
-resident in HBM: labels -> normalise -> forward -> loss -> zero_grad -> backward -> FusedAdam.step, including the one
-host read-back of the four scalars per step.  Prints ONE JSON line (rank 0).
+resident in HBM: labels -> normalise -> forward -> loss -> zero_grad -> backward -> FusedAdam.step.  The four scalars of
+every step (loss, nll, kl, mmd) stay on the device and are read back once, inside the timed region, when ``train``
+returns its per-step lists -- the host never waits for the GPU in the middle of a step.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import importlib

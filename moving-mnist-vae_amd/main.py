@@ -55,22 +55,38 @@ def train(model, data_loader, optimizer, device, args, epoch=0, data_mean=0, dat
     t0 = time.time()
     model.train(True)
     plot_callback = getattr(args, "plot_callback", None)
+    # HIP model: the step scalars stay on the device (model._last_group) and are read back once, after the loop or
+    # when the plot callback needs them -- the host never waits for the GPU in the middle of a step.
+    pending = []                      # (position in the lists, scalar group)
+
+    def materialise():
+        for pos, grp in pending:
+            losses[pos], nlls[pos], kls[pos], mmds[pos] = grp.get(0), grp.get(1), grp.get(2), grp.get(3)
+        pending.clear()
+
     for index, batch in enumerate(data_loader):
         model.train(True)                                                    # main.py:372
         image, target = prepare_batch(model, batch, device, args, data_mean, data_std)
         mu, logvar, encoding, reconstruction = model(image)                  # main.py:389
         loss, nll_v, kl_v, mmd_v = model.loss(target, mu, logvar, encoding, reconstruction, device, args)
-        losses.append(loss.item())                                           # main.py:393
-        nlls.append(nll_v)
-        kls.append(kl_v)
-        mmds.append(mmd_v)
+        grp = getattr(model, "_last_group", None)
+        if grp is not None and getattr(nll_v, "_g", None) is grp:
+            pending.append((len(losses), grp))
+            losses.append(None); nlls.append(None); kls.append(None); mmds.append(None)
+        else:
+            losses.append(loss.item())                                       # main.py:393
+            nlls.append(nll_v)
+            kls.append(kl_v)
+            mmds.append(mmd_v)
         optimizer.zero_grad()                                                # main.py:397-399
         loss.backward()
         optimizer.step()
         if plot_callback is not None and index % plot_every == 0:            # main.py:401
+            materialise()
             plot_callback(model=model, image=image, reconstruction=reconstruction, encoding=encoding,
                           epoch=epoch, index=index, directory=directory,
                           running={"nll": np.mean(nlls), "kl": np.mean(kls), "mmd": np.mean(mmds)})
+    materialise()
     elapsed = time.time() - t0
     if not getattr(args, "quiet", False) and losses:
         print("Epoch={:d}; Loss={:0.5f} NLL={:.3f}; KL={:.3f}; MMD={:.3f}; time_tr={:.1f}s;".format(

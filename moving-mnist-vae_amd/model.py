@@ -120,6 +120,64 @@ class _DecoderFn(torch.autograd.Function):
         return (None, d_enc) + model._grad_views(G, 1)
 
 
+class _StepScalars:
+    """The four scalars of one step (loss, nll/N, kl/N, mmd/N) as a device tensor, copied to the host on first use."""
+    __slots__ = ("dev", "vals")
+
+    def __init__(self, dev_tensor):
+        self.dev, self.vals = dev_tensor, None
+
+    def get(self, i):
+        if self.vals is None:
+            self.vals = self.dev.tolist()        # the only device->host copy (and synchronisation) of the step
+        return self.vals[i]
+
+
+class DeferredScalar:
+    """Float-like view of one step scalar.  ``VAE.loss`` returns these instead of Python floats so that the host does
+    not have to wait for the forward pass before it enqueues the backward pass (the reference synchronises three
+    times per step with ``.item()``); any arithmetic, comparison, formatting or ``float()`` reads the value."""
+    __slots__ = ("_g", "_i")
+
+    def __init__(self, group, index):
+        self._g, self._i = group, index
+
+    def __float__(self):
+        return self._g.get(self._i)
+
+    item = __float__
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __bool__(self):
+        return bool(float(self))
+
+    def __hash__(self):
+        return hash(float(self))
+
+    def __array__(self, dtype=None, copy=None):
+        import numpy as _np
+        return _np.asarray(float(self), dtype=dtype)
+
+
+def _forward_float(name, reflected=False):
+    def op(self, *other):
+        f = getattr(float, name)
+        return f(float(self), *[float(o) if isinstance(o, DeferredScalar) else o for o in other])
+    op.__name__ = name
+    return op
+
+
+for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__pow__", "__rpow__",
+           "__neg__", "__pos__", "__abs__", "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__", "__round__", "__int__",
+           "__floordiv__", "__rfloordiv__", "__mod__", "__rmod__"):
+    setattr(DeferredScalar, _n, _forward_float(_n))
+
+
 class _RsampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu, logvar, eps):
@@ -245,6 +303,7 @@ class VAE(nn.Module):
         d["_stamps"] = {}
         d["_sync"] = None
         d["_last_scalars"] = None
+        d["_last_group"] = None
         d["injected_eps"] = None           # parity tests: noise for rsample / loss instead of torch.randn
         d["injected_true_samples"] = None
         d["_ptable"], d["_btable"] = [], []
@@ -454,8 +513,9 @@ class VAE(nn.Module):
         return acc[0].float()
 
     def loss(self, target, encoding_mu, encoding_logvar, encoding, reconstruction, device, args):
-        """model.py:385-406: returns (loss tensor with grad, nll/N, kl/N, mmd/N as Python floats).
-        One device->host copy of the four scalars instead of the reference's three ``.item()`` calls."""
+        """model.py:385-406: returns (loss tensor with grad, nll/N, kl/N, mmd/N).  The three values are float-like
+        ``DeferredScalar``s: ONE device->host copy of the four scalars, made when a value is first used, instead of
+        the reference's three ``.item()`` synchronisations in the middle of the step."""
         N = target.shape[0]
         dev = reconstruction.device
         categorical = self.decoder_out_channels > self.in_channels
@@ -475,8 +535,9 @@ class VAE(nn.Module):
             if target.dtype != torch.int64:
                 target = target.long()
         loss_t = _LossFn.apply(self, target, encoding_mu, encoding_logvar, enc2, reconstruction, ts, weight)
-        vals = self._last_scalars.tolist()
-        return loss_t, vals[1], vals[2], vals[3]
+        grp = _StepScalars(self._last_scalars)
+        self._last_group = grp
+        return loss_t, DeferredScalar(grp, 1), DeferredScalar(grp, 2), DeferredScalar(grp, 3)
 
     # ---- train-loop hook (main.py:374-388): labels -> normalised frames, one kernel
     def prepare_batch(self, batch, device, data_mean, data_std, categorical):
