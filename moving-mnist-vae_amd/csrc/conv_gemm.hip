@@ -690,6 +690,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 // Returns 1 when the v2 kernel ran, 0 when not eligible, <0 on error.
 static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   if ((conv_force_v1() && !a.P_planar && !a.G_planar) || a.Ca % 16 || a.Cb % 16 || a.ntaps > 25) return 0;
+  if (a.proP_scale && a.proG_scale) return 0;          // one prologue register set in the kernel
   if (a.P_planar && (a.Ca != 16 || a.P_planes > 16 || a.proP_scale)) return 0;
   if (a.G_planar && (a.Cb != 16 || a.Ca != 32 || a.proG_scale || a.ntaps < 4)) return 0;
   auto pick = [](int c) { return c >= 64 ? 64 : c; };
@@ -702,13 +703,22 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   b.proP_scale = a.proP_scale; b.proP_shift = a.proP_shift; b.proP_relu = a.proP_relu;
   b.proG_scale = a.proG_scale; b.proG_shift = a.proG_shift; b.proG_relu = a.proG_relu;
   b.TG = wgrad2_taps_per_block(ta16, tb16, a.ntaps);
+  b.nw = 4;
+  // deep layers (>= 32x64 channel tiles, 3x3 / 4x4 kernels): one tap per wave, every tap in one block -> the tile is
+  // staged once instead of once per tap group
+  static const int nw_env = [] { const char* e = getenv("MMVAE_WGRAD_NW"); return e ? atoi(e) : 1; }();
+  // (only where the 4-wave block needs several tap groups, and not for 64x64 tiles with 16 waves: 128 VGPRs spill)
+  if (nw_env && !a.P_planar && !a.G_planar && ta16 >= 2 && tb16 >= 2 && (a.ntaps == 9 || a.ntaps == 16) && b.TG < a.ntaps &&
+      !(a.ntaps == 16 && ta16 * tb16 >= 16)) {
+    b.nw = a.ntaps; b.TG = a.ntaps;
+  }
   bool fits = false;
   size_t lds = 0;
   for (int TP = 128; TP >= 32 && !fits; TP >>= 1) {     // shrink the pixel tile until patch + P tile fit in LDS
     if (TP < 128 && a.ntaps < 4) break;                 // the k-split mode (1x1 convs) needs all four k-steps
     if (!make_tile_geom(b.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, TP, 1)) continue;
     lds = wgrad2_lds_bytes(b, dt, TA, TB);
-    fits = lds <= kV2MaxLds && wgrad2_patch_slots(b, dt, TB) <= 16;
+    fits = lds <= kV2MaxLds && wgrad2_patch_slots(b, dt, TB) <= (b.nw == 4 ? 16 : 8);
   }
   if (!fits) return 0;
   // big tiles (16x16 channel tile, >= 4 taps, P width a power of two >= 32): fewer, larger tiles amortise the per-tile

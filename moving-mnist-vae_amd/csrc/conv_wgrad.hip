@@ -22,7 +22,8 @@ size_t wgrad2_lds_bytes(const Wgrad2Args& a, int dt, int TA, int TB) {
 // staging slots per thread for the G patch (16-byte vectors / 256 threads)
 int wgrad2_patch_slots(const Wgrad2Args& a, int dt, int TB) {
   const int cvg = TB * (int)dtype_size(dt) / 16;
-  const int per_round = a.G_planar ? 256 : 256 / cvg;
+  const int nt = 64 * (a.nw > 0 ? a.nw : 4);
+  const int per_round = a.G_planar ? nt : nt / cvg;
   const int npatch = a.g.segs * a.g.PR * a.g.PW;
   return (npatch + per_round - 1) / per_round;
 }

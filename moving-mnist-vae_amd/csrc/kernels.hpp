@@ -86,6 +86,7 @@ struct Wgrad2Args {
   int G_planar;            // 1: G is planar T [N][1][Hi][Wi] (the 1-channel image) staged as Cb = 16 zero-padded channels
   int xcd_walk;            // XCD-aware tile order (tile_common.hpp)
   int dbg;                 // developer switches (MMVAE_DBG): 1 skip loads, 2 skip LDS commit, 4 skip MFMA phase
+  int nw;                  // waves per block: 4, or 9 / 16 = one tap per wave (deep 3x3 / 4x4 layers)
   int big, wq_shift;       // big tiles (256 / 512 P-pixels, see conv_wgrad.inc); log2(Wq)
   int partial;             // 1: dW is the partial-image scratch [gridDim.x][ntaps][Ca][Cb] (plain stores); 0: atomics into the weight layout
 };
