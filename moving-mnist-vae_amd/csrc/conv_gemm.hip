@@ -711,6 +711,8 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   if (nw_env && !a.P_planar && !a.G_planar && ta16 >= 2 && tb16 >= 2 && (a.ntaps == 9 || a.ntaps == 16) && b.TG < a.ntaps &&
       !(a.ntaps == 16 && ta16 * tb16 >= 16)) {
     b.nw = a.ntaps; b.TG = a.ntaps;
+  } else if (nw_env && !a.P_planar && !a.G_planar && a.ntaps == 16 && ta16 == 4 && tb16 == 4) {
+    b.nw = 8; b.TG = 16;               // 64x64 tiles, 16 taps: 8 waves x 2 taps (16 waves would spill at 128 VGPRs)
   }
   bool fits = false;
   size_t lds = 0;
