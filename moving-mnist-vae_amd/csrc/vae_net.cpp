@@ -133,7 +133,8 @@ const Plan& Net::plan(int N) {
   P.bnws = take(n_bnws * 4);
   P.partials = take(2 * kPartialFloats * 4);       // second half: the shortcut branch running on the side stream
   for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
-  P.dy1 = take(maxact); P.dy2 = take(maxact); P.dys = take(maxact); P.da1 = take(maxact);
+  for (int i = 0; i < 2; ++i) { P.dy1[i] = take(maxact); P.dy2[i] = take(maxact); P.dys[i] = take(maxact); }
+  P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
   P.wscratch = take((long)kWgradScratchBytes);
   P.bytes = (size_t)cur;
@@ -171,6 +172,7 @@ hipStream_t Net::wgrad_stream(hipStream_t s) {
     if (side_state_ == 1) {
       bool ok = hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) == hipSuccess;
       for (int i = 0; i < 64 && ok; ++i) ok = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreateWithFlags(&blk_ev_[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); side_state_ = -1; }
     }
   }
@@ -186,6 +188,23 @@ int Net::side_join(hipStream_t s) {
   if (wgrad_stream(s) == s) return MMVAE_OK;
   hipEvent_t e = ev_[evi_++ & 63];     // 64 > forks + joins of one backward pass: no event is re-recorded while a wait on it may be pending
   if (hipEventRecord(e, side_) != hipSuccess || hipStreamWaitEvent(s, e, 0) != hipSuccess) { set_error("side stream join failed"); return MMVAE_ERR_HIP; }
+  return MMVAE_OK;
+}
+
+// measured: im2col + 1x1 weight gradient 0.39 ms, planar-G patch-tile path 0.42 ms (MMVAE_STEM_PLANAR=1)
+static bool stem_im2col_path() {
+  static const bool v = [] { const char* e = getenv("MMVAE_STEM_PLANAR"); return !(e && e[0] == '1'); }();
+  return v;
+}
+
+int Net::side_mark(int slot) {
+  if (side_state_ != 1) return MMVAE_OK;
+  if (hipEventRecord(blk_ev_[slot & 7], side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
+  return MMVAE_OK;
+}
+int Net::side_wait_mark(int slot, hipStream_t s) {
+  if (side_state_ != 1) return MMVAE_OK;
+  if (hipStreamWaitEvent(s, blk_ev_[slot & 7], 0) != hipSuccess) { set_error("side stream wait failed"); return MMVAE_ERR_HIP; }
   return MMVAE_OK;
 }
 
@@ -407,6 +426,8 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     a.scratch = wscratch_;
     MM_TRY(side_fork(s));
     MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
+    // the stem's im2col depends on the input image only: early, off the tail of the critical path
+    if (stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
     pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / nt;
@@ -425,7 +446,10 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     const void* xin = i == 0 ? base + P.y0 : base + enc[i - 1].out;
     const float* xs = i == 0 ? bnf(bn0, base, 2) : nullptr;
     const float* xb = i == 0 ? bnf(bn0, base, 3) : nullptr;
-    if (i != 3) MM_TRY(side_join(s));          // the previous block's weight gradients still read dy1 / dy2 / dys
+    // dy1 / dy2 / dys alternate between two sets, so this block only has to wait for the weight gradients of the block
+    // before the previous one (the side stream may lag one block behind)
+    const int ds = i & 1;
+    if (i + 2 <= 3) MM_TRY(side_wait_mark(i + 2, s));
     // join backward: g = d_out * [out > 0] feeds bn2 (y2) and the shortcut BN (ys)
     int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npix, B.C, part, s,
                                   bnf(B.bs, base, 2), bnf(B.bs, base, 3));
@@ -433,48 +457,49 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, cnt, s));
     MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, cnt, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
-                               bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                               base + P.dys, npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
+                               bnf(B.b2, base, 6), base + P.dy2[ds], base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
+                               base + P.dys[ds], npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c2, N, base + P.dy2, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
+    MM_TRY(run_wgrad(B.c2, N, base + P.dy2[ds], B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
                      bnf(B.b1, base, 3), grads, wsm));
-    MM_TRY(run_wgrad(B.cs, N, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
-    MM_TRY(run_up(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
+    MM_TRY(run_wgrad(B.cs, N, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    MM_TRY(run_up(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
     // bn1 + relu backward
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, cnt, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),
-                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix,
+                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1[ds], nullptr, nullptr, nullptr, nullptr, nullptr, npix,
                                B.C, s));
     // conv1 (3x3 s2) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
-    MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
-    MM_TRY(run_up(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
+    MM_TRY(run_wgrad(B.c1, N, base + P.dy1[ds], B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    MM_TRY(side_mark(i));
+    MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
+    MM_TRY(run_up(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     cur ^= 1;
   }
   // ---- stem: bn0 + relu backward, then the 5x5 weight gradient
-  MM_TRY(side_join(s));            // block 0's conv1 weight gradient still reads dy1
+  MM_TRY(side_wait_mark(1, s));    // the stem uses dy set 1 (block index -1): block 1's weight gradients read it last
+  const int ds = 1;
   {
     const long npix = (long)N * H1 * W1;
     int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, nullptr, npix, 32, part, s);
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(bn0, params, grads, base, np, 1, 0, (double)npix, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(bn0, base, 2), bnf(bn0, base, 3), base + P.y0, bnf(bn0, base, 4),
-                               bnf(bn0, base, 5), bnf(bn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 32, s));
-    // measured: im2col + 1x1 weight gradient 0.39 ms, planar-G patch-tile path 0.42 ms (MMVAE_STEM_PLANAR=1)
-    static const bool stem_im2col = [] { const char* e = getenv("MMVAE_STEM_PLANAR"); return !(e && e[0] == '1'); }();
+                               bnf(bn0, base, 5), bnf(bn0, base, 6), base + P.dy1[ds], nullptr, nullptr, nullptr, nullptr, nullptr, npix, 32, s));
+    const bool stem_im2col = stem_im2col_path();
     MM_TRY(side_fork(s));
     hipStream_t wsm = wgrad_stream(s);
     WgradArgs a; std::memset(&a, 0, sizeof(a));
-    a.P = base + P.dy1; a.dW = grads + stem.off; a.scratch = wscratch_;
+    a.P = base + P.dy1[ds]; a.dW = grads + stem.off; a.scratch = wscratch_;
     a.N = N; a.Hp = H1; a.Wp = W1; a.Ca = 32; a.scale = 1.f;
     if (stem_im2col) {
       // im2col of the 1-channel image (25 taps padded to 32 columns) + the MFMA weight-gradient kernel as a 1x1 conv
-      MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wsm));
+      if (wsm == s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wsm));   // else: done early
       a.G = base + P.col; a.Hg = H1; a.Wg = W1; a.Cb = 32; a.Cb_valid = 25;
       a.stride = 1; a.pad = 0; a.ksz = 1; a.sA = 25; a.sB = 1; a.ntaps = 1;
     } else {
@@ -618,49 +643,52 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     const void* xin = i == 0 ? base + P.y0d : base + dec[i - 1].out;
     const float* xs = i == 0 ? bnf(dbn0, base, 2) : nullptr;
     const float* xb = i == 0 ? bnf(dbn0, base, 3) : nullptr;
-    if (i != nup - 1) MM_TRY(side_join(s));    // the previous block's weight gradients still read dy1 / dy2 / dys
+    const int ds = i & 1;          // dy set of this block (see encoder_bwd)
+    if (i + 2 <= nup - 1) MM_TRY(side_wait_mark(i + 2, s));
     np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
                               bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
     MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, (double)npo, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
-                               bnf(B.b2, base, 6), base + P.dy2, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                               base + P.dys, npo, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
+                               bnf(B.b2, base, 6), base + P.dy2[ds], base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
+                               base + P.dys[ds], npo, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2, B.Hout, B.Wout, nullptr,
+    MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2[ds], B.Hout, B.Wout, nullptr,
                      nullptr, grads, wsm));
-    MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys, B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
-    MM_TRY(run_down(B.c2, base, N, base + P.dy2, B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
+    MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
+    MM_TRY(run_down(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, (double)npi, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),
-                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npi,
+                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1[ds], nullptr, nullptr, nullptr, nullptr, nullptr, npi,
                                B.C, s));
     // conv1 (1x1): wgrad(P = dy1, G = xin); upsample (ConvT): wgrad(P = xin, G = dys)
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c1, N, base + P.dy1, B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    MM_TRY(run_wgrad(B.c1, N, base + P.dy1[ds], B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    MM_TRY(side_mark(i));
     // d_xin = dgrad(conv1)(dy1) + dgrad(upsample)(dys)
-    MM_TRY(run_up(B.c1, base, N, base + P.dy1, B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
-    MM_TRY(run_down(B.cs, base, N, base + P.dys, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, dt(), s));
+    MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
+    MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, dt(), s));
     cur ^= 1;
   }
   // ---- decoder stem
-  MM_TRY(side_join(s));            // up-block 0's conv1 weight gradient still reads dy1
+  if (nup >= 2) MM_TRY(side_wait_mark(1, s));   // the stem uses dy set 1 (block index -1)
+  const int ds = 1;
   {
     const long npix = (long)N * 4;
     np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(dbn0, base, 2), bnf(dbn0, base, 3), base + P.y0d, nullptr, npix, 128, part, s);
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(dbn0, params, grads, base, np, 1, 0, (double)npix, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(dbn0, base, 2), bnf(dbn0, base, 3), base + P.y0d, bnf(dbn0, base, 4),
-                               bnf(dbn0, base, 5), bnf(dbn0, base, 6), base + P.dy1, nullptr, nullptr, nullptr, nullptr, nullptr, npix, 128, s));
+                               bnf(dbn0, base, 5), bnf(dbn0, base, 6), base + P.dy1[ds], nullptr, nullptr, nullptr, nullptr, nullptr, npix, 128, s));
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(dstem, N, base + P.enc_t, 1, 1, nullptr, nullptr, base + P.dy1, 2, 2, nullptr, nullptr, grads, wgrad_stream(s)));
+    MM_TRY(run_wgrad(dstem, N, base + P.enc_t, 1, 1, nullptr, nullptr, base + P.dy1[ds], 2, 2, nullptr, nullptr, grads, wgrad_stream(s)));
     if (d_enc) {
-      MM_TRY(run_down(dstem, base, N, base + P.dy1, 2, 2, base + P.dh, 1, 1, nullptr, nullptr, 0, nullptr, 0, dt(), s));
+      MM_TRY(run_down(dstem, base, N, base + P.dy1[ds], 2, 2, base + P.dh, 1, 1, nullptr, nullptr, 0, nullptr, 0, dt(), s));
       MM_TRY(launch_convert(dt(), DT_F32, base + P.dh, d_enc, (long)N * cfg.z, s));
     }
     MM_TRY(side_join(s));

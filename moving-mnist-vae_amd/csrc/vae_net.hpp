@@ -34,7 +34,8 @@ struct Plan {
   long packed;                                           // packed weights (T)
   long bnws;                                             // float scratch for all BNs
   long partials;                                         // reduction partials (floats)
-  long g[2], dy1, dy2, dys, da1, dh;                     // backward temporaries
+  long g[2], dy1[2], dy2[2], dys[2], da1, dh;            // backward temporaries (dy*: two sets, alternating per block, so the
+                                                         // weight gradients on the side stream may lag one block behind)
   long wscratch;                                         // [tap][a][b] reduction image of the largest weight gradient
   long enc_ws_end;
 };
@@ -82,6 +83,9 @@ class Net {
   hipStream_t wgrad_stream(hipStream_t s);      // stream the weight gradients are enqueued on
   int side_fork(hipStream_t s);                 // side stream waits for everything enqueued on s so far
   int side_join(hipStream_t s);                 // s waits for everything enqueued on the side stream so far
+  hipEvent_t blk_ev_[8] = {};                   // side-stream progress marks, one per block of a backward pass
+  int side_mark(int slot);                      // record mark `slot` on the side stream
+  int side_wait_mark(int slot, hipStream_t s);  // s waits for mark `slot`
   int dt() const { return cfg.dtype; }
   size_t esz() const { return dtype_size(cfg.dtype); }
   ConvW add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack);
