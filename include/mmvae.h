@@ -125,6 +125,7 @@ MMVAE_API int mmvae_adam_step(float* params, const float* grads, float* exp_avg,
  * Conv2d / ConvTranspose2d with PyTorch weight layouts on NHWC activations of `dtype`:
  *   x [N,H,W,Cin], y [N,Ho,Wo,Cout];  weight f32 (Cout,Cin,k,k) for Conv2d, (Cin,Cout,k,k) for ConvTranspose2d.
  * scratch: device buffer of at least 2*numel(weight)*sizeof(dtype)+64 bytes for the packed weights.
+ * mmvae_conv2d_fwd with weight == NULL reuses the packed weights an earlier call with the same geometry left in `scratch`.
  * pro_scale/pro_shift (per input channel, nullable): x := relu?(x*scale+shift) applied on load (fused BN+ReLU).
  * stats (nullable): per-channel (sum,sumsq) partials [rows][2][Cout]; the call returns `rows`. */
 MMVAE_API int mmvae_conv2d_fwd(int dtype, int transposed, const void* x, const float* weight, void* y, int N, int H, int W, int Cin, int Cout,

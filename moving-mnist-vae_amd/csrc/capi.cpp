@@ -144,11 +144,12 @@ int mmvae_conv2d_fwd(int dt, int transposed, const void* x, const float* w, void
                      int s, int p, const float* ps, const float* pb, int relu, float* stats, void* scratch, void* st) {
   const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
   const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
+  // weight == NULL: `scratch` still holds the packed weights of an earlier call with the same geometry (pack once, run many)
   if (!transposed) {
-    int rc = op_pack_down(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
+    if (w) { int rc = op_pack_down(dt, g, w, scratch, S(st)); if (rc < 0) return rc; }
     return op_run_down(dt, dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st));
   }
-  int rc = op_pack_up(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
+  if (w) { int rc = op_pack_up(dt, g, w, scratch, S(st)); if (rc < 0) return rc; }
   return op_run_up(dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st));
 }
 int mmvae_conv2d_dgrad(int dt, int transposed, const void* dy, const float* w, void* dx, int N, int H, int W, int Cin, int Cout, int k,
