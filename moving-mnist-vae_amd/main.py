@@ -68,7 +68,10 @@ def train(model, data_loader, optimizer, device, args, epoch=0, data_mean=0, dat
         model.train(True)                                                    # main.py:372
         image, target = prepare_batch(model, batch, device, args, data_mean, data_std)
         mu, logvar, encoding, reconstruction = model(image)                  # main.py:389
-        loss, nll_v, kl_v, mmd_v = model.loss(target, mu, logvar, encoding, reconstruction, device, args)
+        if hasattr(model, "_last_group"):      # HIP model: scalars stay on the device until the end of the loop
+            loss, nll_v, kl_v, mmd_v = model.loss(target, mu, logvar, encoding, reconstruction, device, args, deferred=True)
+        else:
+            loss, nll_v, kl_v, mmd_v = model.loss(target, mu, logvar, encoding, reconstruction, device, args)
         grp = getattr(model, "_last_group", None)
         if grp is not None and getattr(nll_v, "_g", None) is grp:
             pending.append((len(losses), grp))

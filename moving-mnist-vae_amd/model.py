@@ -512,10 +512,11 @@ class VAE(nn.Module):
         check(lib().mmvae_mmd_fwd(ptr(x), ptr(y), x.shape[0], x.shape[1], None, ptr(acc), _stream()), "mmvae_mmd_fwd")
         return acc[0].float()
 
-    def loss(self, target, encoding_mu, encoding_logvar, encoding, reconstruction, device, args):
-        """model.py:385-406: returns (loss tensor with grad, nll/N, kl/N, mmd/N).  The three values are float-like
-        ``DeferredScalar``s: ONE device->host copy of the four scalars, made when a value is first used, instead of
-        the reference's three ``.item()`` synchronisations in the middle of the step."""
+    def loss(self, target, encoding_mu, encoding_logvar, encoding, reconstruction, device, args, deferred=False):
+        """model.py:385-406: returns (loss tensor with grad, nll/N, kl/N, mmd/N as Python floats) -- ONE device->host
+        copy of the four scalars instead of the reference's three ``.item()`` calls.  ``deferred=True`` (used by this
+        package's ``train``) returns float-like ``DeferredScalar``s instead, read back when first used, so that the host
+        does not wait for the forward pass before it enqueues the backward pass."""
         N = target.shape[0]
         dev = reconstruction.device
         categorical = self.decoder_out_channels > self.in_channels
@@ -537,7 +538,9 @@ class VAE(nn.Module):
         loss_t = _LossFn.apply(self, target, encoding_mu, encoding_logvar, enc2, reconstruction, ts, weight)
         grp = _StepScalars(self._last_scalars)
         self._last_group = grp
-        return loss_t, DeferredScalar(grp, 1), DeferredScalar(grp, 2), DeferredScalar(grp, 3)
+        if deferred:
+            return loss_t, DeferredScalar(grp, 1), DeferredScalar(grp, 2), DeferredScalar(grp, 3)
+        return loss_t, grp.get(1), grp.get(2), grp.get(3)
 
     # ---- train-loop hook (main.py:374-388): labels -> normalised frames, one kernel
     def prepare_batch(self, batch, device, data_mean, data_std, categorical):
