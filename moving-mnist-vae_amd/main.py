@@ -60,6 +60,9 @@ def train(model, data_loader, optimizer, device, args, epoch=0, data_mean=0, dat
     pending = []                      # (position in the lists, scalar group)
 
     def materialise():
+        sync = getattr(model, "_sync", None)
+        if sync is not None and pending:       # data parallel: the logged values are means over ranks (one message)
+            sync.reduce_step_scalars([g for _, g in pending])
         for pos, grp in pending:
             losses[pos], nlls[pos], kls[pos], mmds[pos] = grp.get(0), grp.get(1), grp.get(2), grp.get(3)
         pending.clear()

@@ -690,6 +690,17 @@ class GradSync:
         self.handles.append(self.dist.all_reduce(G[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.reduced.append((lo, hi))
 
+    def reduce_step_scalars(self, groups):
+        """Logged scalars of data-parallel training: ONE all-reduce of the stacked (steps, 4) device tensor, mean over
+        ranks.  `groups` are the _StepScalars of the steps not yet read back."""
+        if self.world == 1 or not groups:
+            return
+        stacked = torch.stack([g.dev for g in groups])
+        self.dist.all_reduce(stacked, op=self.dist.ReduceOp.SUM, group=self.group)
+        vals = (stacked / self.world).tolist()
+        for g, v in zip(groups, vals):
+            g.vals = v
+
     def finish(self, G):
         """Wait for the in-flight buckets; returns the factor Adam applies to the summed gradient."""
         for h in self.handles:

@@ -45,6 +45,11 @@ def _cpu_worker(rank, world, port, q):
         sync.bucket_ready(G2, dec_off, n)
         sync.finish(G2)
         assert torch.all(G2 == 3.0)
+        # logged step scalars: one all-reduce of the stacked (steps, 4) tensor, mean over ranks
+        groups = [M._StepScalars(torch.tensor([1.0, 2.0, 3.0, 4.0]) * (rank + 1) * (k + 1)) for k in range(3)]
+        sync.reduce_step_scalars(groups)
+        for k, g in enumerate(groups):
+            assert g.get(0) == 1.5 * (k + 1) and g.get(3) == 6.0 * (k + 1), g.vals
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, repr(e)))
