@@ -420,7 +420,7 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   }
   if (!ok) return 0;
   int occ = (int)((160 * 1024) / lds);
-  const int occ_regs = slots <= 4 ? (ct16 == 1 ? 4 : (ct16 == 2 ? 3 : 2)) : 2;
+  const int occ_regs = slots <= 4 ? (ct16 == 1 ? 4 : (ct16 == 2 ? 3 : 2)) : ((slots <= 8 && ct16 == 1 && !a.x_planar) ? 3 : 2);
   if (occ > occ_regs) occ = occ_regs;
   if (occ < 1) occ = 1;
   int gx = 256 * occ;
