@@ -420,6 +420,337 @@ int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* 
                       : launch_bn_bwd_apply_t<bf16_t>(dout, out, msk_scale, msk_shift, msk_scale1, msk_shift1, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, npix, C, s);
 }
 
+// ---------------------------------------------------------------- last up-block: join backward fused with the tail dgrad
+// The gradient entering the last up-block is a 3x3 convolution of the reconstruction gradient d_raw (out_ch <= 8 planes,
+// f32 NCHW) with the tail weights:  g[n,h,w,ci] = sum_{oc,kh,kw} d_raw[n,oc,h+1-kh,w+1-kw] * w[oc][ci][kh][kw].
+// Materialising it costs a 671 MB write and two 671 MB reads (reduce + apply) at N = 5120; recomputing it from the 8x
+// smaller d_raw inside the two BatchNorm-backward passes costs 72 FMAs per 16-byte vector and almost no HBM traffic.
+// C = 16 channels (the tail conv's input).  Same mask / coefficient arithmetic as bn_bwd_reduce/apply MODE 3, NY = 2.
+//
+// A block walks tiles of 256 consecutive 16-byte vectors = PT = 256/cvecs consecutive pixels = R = PT/W whole image rows
+// (the host checks W is a power of two <= PT and H*W % PT == 0, so a tile never straddles images).  The R+2 rows of d_raw a
+// tile needs go through a double-buffered LDS tile with zero halo columns: one barrier per tile, no per-thread divisions.
+// OC == 1 (Moving MNIST) keeps the thread's 9 x VE weights in registers (bf16 pairs when T is bf16: the same rounding the
+// MFMA dgrad applies); OC > 1 reads them from LDS.
+struct TailG { const float* d_raw; const float* w; int OC, H, W, wshift; int ntiles; };
+
+template <typename T> struct TailW;
+template <> struct TailW<float> {
+  float v[9][4];
+  __device__ __forceinline__ void load(const float* w, int c0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[t][j] = w[(c0 + j) * 9 + t];
+  }
+  __device__ __forceinline__ void fma(int t, float d, float (&g)[4]) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] += d * v[t][j];
+  }
+};
+template <> struct TailW<bf16_t> {
+  uint32_t v[9][4];
+  __device__ __forceinline__ void load(const float* w, int c0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[t][j] = pack2_bf16(w[(c0 + 2 * j) * 9 + t], w[(c0 + 2 * j + 1) * 9 + t]);
+  }
+  __device__ __forceinline__ void fma(int t, float d, float (&g)[8]) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t pw = v[t][j];
+      asm volatile("" : "+v"(pw));        // keep the pair packed across iterations: a hoisted unpack doubles the registers
+      g[2 * j] += d * __uint_as_float(pw << 16);
+      g[2 * j + 1] += d * __uint_as_float(pw & 0xffff0000u);
+    }
+  }
+};
+
+template <typename T, bool OC1, bool APPLY>
+__global__ __launch_bounds__(256, OC1 ? 3 : 2) void tail_join_bwd_kernel(TailG tg, const float* __restrict__ ms, const float* __restrict__ mb,
+                                                            const float* __restrict__ ms1, const float* __restrict__ mb1,
+                                                            const T* __restrict__ y0, const float* __restrict__ A0, const float* __restrict__ B0,
+                                                            const float* __restrict__ C0, T* __restrict__ dy0, const T* __restrict__ y1,
+                                                            const float* __restrict__ A1, const float* __restrict__ B1,
+                                                            const float* __restrict__ C1, T* __restrict__ dy1, float* __restrict__ partials) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int CV = 16 / VE, PT = 256 / CV;
+  extern __shared__ float smem[];
+  const int W = tg.W, H = tg.H, hw = H * W, OC = tg.OC;
+  const int R = PT >> tg.wshift, pitch = W + 2, rows = R + 2;
+  const int tile_floats = OC * rows * pitch;
+  float* sD = smem;                                  // [2][OC][rows][pitch]
+  float* sW = smem + 2 * tile_floats;                // [OC][9][16] (OC > 1 only)
+  const int tid = threadIdx.x, cg = tid % CV, p = tid / CV;
+  const int pr = p >> tg.wshift, pc = p & (W - 1);
+  for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;     // halo columns stay zero for the kernel's lifetime
+  TailW<T> wr;
+  if (OC1) wr.load(tg.w, cg * VE);
+  else
+    for (int i = tid; i < OC * 144; i += 256) {      // w[oc][ci][tap] -> sW[oc][tap][ci]
+      const int oc = i / 144, rem = i - oc * 144, ci = rem / 9, t = rem - ci * 9;
+      sW[(oc * 9 + t) * 16 + ci] = tg.w[i];
+    }
+  float msc[VE], msh[VE], msc1[VE], msh1[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) { const int ch = cg * VE + j; msc[j] = ms[ch]; msh[j] = mb[ch]; msc1[j] = ms1[ch]; msh1[j] = mb1[ch]; }
+  float a0[VE], b0[VE];
+  float acc[3][VE];
+  float* sC = sW + (OC1 ? 0 : OC * 144);            // [4][16] C0, C1, A1, B1 (APPLY: keeps the kernel under 168 VGPRs)
+#pragma unroll
+  for (int j = 0; j < VE; ++j) {
+    const int ch = cg * VE + j;
+    if (APPLY) { a0[j] = A0[ch]; b0[j] = B0[ch]; }
+    else { acc[0][j] = 0.f; acc[1][j] = 0.f; acc[2][j] = 0.f; }
+  }
+  if (APPLY && tid < 64) sC[tid] = (tid < 16 ? C0 : (tid < 32 ? C1 : (tid < 48 ? A1 : B1)))[tid & 15];
+  __syncthreads();
+  const int stage = rows * W;                        // d_raw elements per plane per tile (<= 3 * PT = 2 per thread)
+  int buf = 0;
+  Vec16 q0, q1;                                      // the tile's y vectors and (OC == 1) d_raw rows, loaded one tile ahead
+  float dpre[2] = {0.f, 0.f};
+  auto fetch = [&](int t) {
+    const long v = (long)t * 256 + tid;
+    q0 = reinterpret_cast<const Vec16*>(y0)[v];
+    q1 = reinterpret_cast<const Vec16*>(y1)[v];
+    if (OC1) {
+      const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;      // uniform
+      const float* dp = tg.d_raw + (long)n * hw;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + k * 256, r = e >> tg.wshift, c = e & (W - 1), h = h0 - 1 + r;
+        dpre[k] = (e < stage && h >= 0 && h < H) ? dp[h * W + c] : 0.f;
+      }
+    }
+  };
+  if ((int)blockIdx.x < tg.ntiles) fetch(blockIdx.x);
+  for (int t = blockIdx.x; t < tg.ntiles; t += gridDim.x, buf ^= 1) {
+    float* sT = sD + buf * tile_floats;
+    // rows h0-1 .. h0+R of every plane -> LDS
+    if (OC1) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + k * 256, r = e >> tg.wshift, c = e & (W - 1);
+        if (e < stage) sT[r * pitch + c + 1] = dpre[k];
+      }
+    } else {
+      const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;        // uniform
+      for (int oc = 0; oc < OC; ++oc) {
+        const float* dp = tg.d_raw + ((long)n * OC + oc) * hw;
+        for (int e = tid; e < stage; e += 256) {
+          const int r = e >> tg.wshift, c = e & (W - 1), h = h0 - 1 + r;
+          sT[(oc * rows + r) * pitch + c + 1] = (h >= 0 && h < H) ? dp[h * W + c] : 0.f;
+        }
+      }
+    }
+    const long v = (long)t * 256 + tid;
+    float f0[VE], f1[VE];
+    Elem<T>::unpack(q0, f0);
+    Elem<T>::unpack(q1, f1);
+    if (t + (int)gridDim.x < tg.ntiles) fetch(t + gridDim.x);
+    __syncthreads();
+    float g[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) g[j] = 0.f;
+    if (OC1) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) wr.fma(kh * 3 + kw, sT[(pr + 2 - kh) * pitch + pc + 2 - kw], g);
+    } else {
+      for (int oc = 0; oc < OC; ++oc)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float d = sT[(oc * rows + pr + 2 - kh) * pitch + pc + 2 - kw];
+            const float* wp = sW + (oc * 9 + kh * 3 + kw) * 16 + cg * VE;
+#pragma unroll
+            for (int j = 0; j < VE; ++j) g[j] += d * wp[j];
+          }
+    }
+    if (APPLY) {
+      float r0[VE], r1[VE];
+      int co = cg * VE;
+      asm volatile("" : "+v"(co));          // re-read per tile: hoisted, the 2 x VE values cost the registers LDS was meant to save
+      const float* c0 = sC + co;
+      const float *c1 = sC + 16 + co, *a1 = sC + 32 + co, *b1 = sC + 48 + co;
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        const float x = (f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]);
+        const float gg = x > 0.f ? g[j] : 0.f;
+        r0[j] = a0[j] * gg + b0[j] * f0[j] + c0[j];
+        r1[j] = a1[j] * gg + b1[j] * f1[j] + c1[j];
+      }
+      reinterpret_cast<Vec16*>(dy0)[v] = Elem<T>::pack(r0);
+      reinterpret_cast<Vec16*>(dy1)[v] = Elem<T>::pack(r1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        const float x = (f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]);
+        const float gg = x > 0.f ? g[j] : 0.f;
+        acc[0][j] += gg; acc[1][j] += gg * f0[j]; acc[2][j] += gg * f1[j];
+      }
+    }
+  }
+  if (!APPLY) {
+    __syncthreads();
+    block_channel_reduce<3, VE>(acc, CV, 16, sC, partials + (long)blockIdx.x * 3 * 16);
+  }
+}
+
+// Whether the tile walk above covers an (OC, H, W) output with element type dt; the caller keeps the separate dgrad otherwise.
+bool tail_join_fusable(int dt, int OC, int N, int H, int W) {
+  const int cv = dt == DT_F32 ? 4 : 2, pt = 256 / cv;
+  if (OC < 1 || OC > 8 || W < 1 || (W & (W - 1)) || W > pt) return false;
+  if (((long)H * W) % pt) return false;
+  return (long)N * H * W / pt < (1L << 30);
+}
+
+template <bool APPLY>
+static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
+                            const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
+                            const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, float* partials, hipStream_t s) {
+  if (!tail_join_fusable(dt, OC, N, H, W)) { set_error("tail_join_bwd: OC=%d H=%d W=%d not supported", OC, H, W); return MMVAE_ERR_UNSUPPORTED; }
+  const int VE = dt == DT_F32 ? 4 : 8, cv = 16 / VE, pt = 256 / cv;
+  int wshift = 0;
+  while ((1 << wshift) < W) ++wshift;
+  const int ntiles = (int)((long)N * H * W / pt);
+  int blocks = ntiles < (APPLY ? kElemMaxBlocks : 1024) ? ntiles : (APPLY ? kElemMaxBlocks : 1024);
+  const TailG tg{d_raw, w, OC, H, W, wshift, ntiles};
+  const int tile_floats = OC * (pt / W + 2) * (W + 2);
+  const size_t sm = ((size_t)2 * tile_floats + (OC == 1 ? 0 : OC * 144) + (APPLY ? 64 : 256 * 3 * VE)) * sizeof(float);
+#define MMVAE_LAUNCH(T, OC1) hipLaunchKernelGGL((tail_join_bwd_kernel<T, OC1, APPLY>), dim3(blocks), dim3(256), sm, s, tg, ms, mb, ms1, mb1, \
+    (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, partials)
+  if (dt == DT_F32) { if (OC == 1) MMVAE_LAUNCH(float, true); else MMVAE_LAUNCH(float, false); }
+  else { if (OC == 1) MMVAE_LAUNCH(bf16_t, true); else MMVAE_LAUNCH(bf16_t, false); }
+#undef MMVAE_LAUNCH
+  const int rc = check_launch(APPLY ? "tail_join_bwd_apply" : "tail_join_bwd_reduce");
+  return rc ? rc : blocks;
+}
+
+int launch_tail_join_bwd_reduce(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
+                                const float* ms1, const float* mb1, const void* y0, const void* y1, float* partials, hipStream_t s) {
+  return launch_tail_join<false>(dt, d_raw, w, OC, N, H, W, ms, mb, ms1, mb1, y0, nullptr, nullptr, nullptr, nullptr, y1, nullptr, nullptr, nullptr,
+                                 nullptr, partials, s);
+}
+
+int launch_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
+                               const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
+                               const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, hipStream_t s) {
+  const int rc = launch_tail_join<true>(dt, d_raw, w, OC, N, H, W, ms, mb, ms1, mb1, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, nullptr, s);
+  return rc < 0 ? rc : MMVAE_OK;
+}
+
+// ---------------------------------------------------------------- tail conv weight gradient, one output plane
+// dW[0][ci][kh][kw] = sum_{n,h,w} out[n,h,w,ci] * d_raw[n, h+1-kh, w+1-kw]: the same tile walk and LDS d_raw tile as the join
+// backward above, with 9 x VE accumulators per thread instead of an MFMA tile (a 16 x 9 result over 21 M pixels is a
+// reduction, not a GEMM: the MFMA wgrad spends its time transposing operands and reaches 1.4 TB/s on it).
+// Deterministic: per-block partials [block][144] in (ci, tap) order, summed by tail_wgrad_finalize_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T* __restrict__ x, float* __restrict__ partials) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int CV = 16 / VE, PT = 256 / CV;
+  extern __shared__ float smem[];
+  const int W = tg.W, H = tg.H, hw = H * W;
+  const int R = PT >> tg.wshift, pitch = W + 2, rows = R + 2;
+  const int tile_floats = rows * pitch;
+  float* sD = smem;                                  // [2][rows][pitch]
+  float* sR = smem + 2 * tile_floats;                // [4 waves][CV][9 * VE]
+  const int tid = threadIdx.x, p = tid / CV;
+  const int pr = p >> tg.wshift, pc = p & (W - 1);
+  for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;
+  float acc[9][VE];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < VE; ++j) acc[t][j] = 0.f;
+  __syncthreads();
+  const int stage = rows * W;
+  const int G = gridDim.x;
+  Vec16 q[2];                                        // x vectors of the next two tiles
+  float dpre[2] = {0.f, 0.f};
+  auto fetch_d = [&](int t) {
+    const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;      // uniform
+    const float* dp = tg.d_raw + (long)n * hw;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * 256, r = e >> tg.wshift, c = e & (W - 1), h = h0 - 1 + r;
+      dpre[k] = (e < stage && h >= 0 && h < H) ? dp[h * W + c] : 0.f;
+    }
+  };
+  const int t0 = blockIdx.x;
+  if (t0 < tg.ntiles) { q[0] = reinterpret_cast<const Vec16*>(x)[(long)t0 * 256 + tid]; fetch_d(t0); }
+  if (t0 + G < tg.ntiles) q[1] = reinterpret_cast<const Vec16*>(x)[(long)(t0 + G) * 256 + tid];
+  int buf = 0;
+  for (int t = t0; t < tg.ntiles; t += G, buf ^= 1) {
+    float* sT = sD + buf * tile_floats;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * 256, r = e >> tg.wshift, c = e & (W - 1);
+      if (e < stage) sT[r * pitch + c + 1] = dpre[k];
+    }
+    float f[VE];
+    Elem<T>::unpack(q[0], f);
+    q[0] = q[1];
+    if (t + G < tg.ntiles) fetch_d(t + G);
+    if (t + 2 * G < tg.ntiles) q[1] = reinterpret_cast<const Vec16*>(x)[(long)(t + 2 * G) * 256 + tid];
+    __syncthreads();
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float d = sT[(pr + 2 - kh) * pitch + pc + 2 - kw];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) acc[kh * 3 + kw][j] += d * f[j];
+      }
+  }
+  // lanes with equal (lane % CV) share channels: butterfly over the other lane bits, then the four waves through LDS
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+      float v = acc[t][j];
+#pragma unroll
+      for (int m = CV; m < 64; m <<= 1) v += __shfl_xor(v, m);
+      if (lane < CV) sR[(wv * CV + lane) * 9 * VE + t * VE + j] = v;
+    }
+  __syncthreads();
+  if (tid < 144) {
+    const int ci = tid / 9, t = tid - ci * 9, cg = ci / VE, j = ci - cg * VE;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += sR[(w * CV + cg) * 9 * VE + t * VE + j];
+    partials[(long)blockIdx.x * 144 + tid] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void tail_wgrad_finalize_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ dW) {
+  double s = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += 64) s += (double)partials[(long)p * 144 + blockIdx.x];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) dW[blockIdx.x] += (float)s;
+}
+
+// x = the tail conv's input (NHWC, 16 channels), d_raw = its output gradient (one f32 plane); dW[16][3][3] is accumulated into.
+// scratch: at least 1024 * 144 floats.  The geometry must pass tail_join_fusable(dt, 1, N, H, W).
+int launch_tail_wgrad_tile(int dt, const void* x, const float* d_raw, float* dW, float* scratch, int N, int H, int W, hipStream_t s) {
+  if (!tail_join_fusable(dt, 1, N, H, W)) { set_error("tail_wgrad_tile: H=%d W=%d not supported", H, W); return MMVAE_ERR_UNSUPPORTED; }
+  const int VE = dt == DT_F32 ? 4 : 8, cv = 16 / VE, pt = 256 / cv;
+  int wshift = 0;
+  while ((1 << wshift) < W) ++wshift;
+  const int ntiles = (int)((long)N * H * W / pt);
+  const int blocks = ntiles < 1024 ? ntiles : 1024;
+  const TailG tg{d_raw, nullptr, 1, H, W, wshift, ntiles};
+  const size_t sm = ((size_t)2 * (pt / W + 2) * (W + 2) + 4 * cv * 9 * VE) * sizeof(float);
+  if (dt == DT_F32) hipLaunchKernelGGL((tail_wgrad_tile_kernel<float>), dim3(blocks), dim3(256), sm, s, tg, (const float*)x, scratch);
+  else hipLaunchKernelGGL((tail_wgrad_tile_kernel<bf16_t>), dim3(blocks), dim3(256), sm, s, tg, (const bf16_t*)x, scratch);
+  hipLaunchKernelGGL(tail_wgrad_finalize_kernel, dim3(144), dim3(64), 0, s, scratch, blocks, dW);
+  return check_launch("tail_wgrad_tile");
+}
+
 // ---------------------------------------------------------------- NCHW f32 elementwise (output BN)
 __global__ void affine_nchw_kernel(const float* __restrict__ raw, const float* __restrict__ scale, const float* __restrict__ shift,
                                    float* __restrict__ out, long total, int C, int HW) {

@@ -608,8 +608,13 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s,
                                   grads + tail_bias));
   static const bool tail_wgrad_direct = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_DIRECT"); return e && e[0] == '1'; }();
+  // one output plane: a tiled VALU reduction (launch_tail_wgrad_tile) beats the MFMA wgrad; MMVAE_TAIL_WGRAD_TILE=0 disables it
+  static const bool tail_wgrad_tile_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_TILE"); return !(e && e[0] == '0'); }();
   if (tail_wgrad_direct) {
     MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, nullptr, N, Sd, Sd, cfg.out_ch, s));
+  } else if (tail_wgrad_tile_env && cfg.out_ch == 1 && nup >= 1 && tail_join_fusable(dt(), 1, N, Sd, Sd)) {
+    MM_TRY(side_fork(s));
+    MM_TRY(launch_tail_wgrad_tile(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, wscratch_, N, Sd, Sd, wgrad_stream(s)));
   } else {
     // dW[oc][ci][kh][kw]: P = d_raw (planar f32, out_ch planes staged as 16 zero-padded channels), G = the last up-block's output
     WgradArgs a; std::memset(&a, 0, sizeof(a));
@@ -622,7 +627,12 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   }
   int cur = 0;
   static const bool tail_direct = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
-  if (tail_direct) {
+  // The tail conv's input gradient is not materialised: the last up-block's join backward recomputes it from d_raw
+  // (launch_tail_join_bwd_*; MMVAE_TAIL_FUSED=0 restores the separate dgrad kernel).
+  static const bool tail_fused_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
+  const bool tail_fused = tail_fused_env && nup >= 1 && dec[nup - 1].C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
+  if (tail_fused) {
+  } else if (tail_direct) {
     MM_TRY(launch_tail_dgrad(dt(), d_raw, params + tail.off, base + P.g[cur], N, Sd, Sd, cfg.out_ch, s));
   } else {
     // dx[n,h,w,ci] = sum dy[n,oc,h+1-kh,w+1-kw] * w[oc][ci][kh][kw]: planar f32 source padded to 8 channels in LDS
@@ -645,14 +655,24 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     const float* xb = i == 0 ? bnf(dbn0, base, 3) : nullptr;
     const int ds = i & 1;          // dy set of this block (see encoder_bwd)
     if (i + 2 <= nup - 1) MM_TRY(side_wait_mark(i + 2, s));
-    np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
-                              bnf(B.bs, base, 2), bnf(B.bs, base, 3));
+    const bool from_tail = tail_fused && i == nup - 1;
+    if (from_tail)
+      np = launch_tail_join_bwd_reduce(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
+                                       bnf(B.bs, base, 3), base + B.y2, base + B.ys, part, s);
+    else
+      np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
+                                bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
     MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, (double)npo, s));
-    MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
-                               bnf(B.b2, base, 6), base + P.dy2[ds], base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                               base + P.dys[ds], npo, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
+    if (from_tail)
+      MM_TRY(launch_tail_join_bwd_apply(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
+                                        bnf(B.bs, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5), bnf(B.b2, base, 6), base + P.dy2[ds],
+                                        base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6), base + P.dys[ds], s));
+    else
+      MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
+                                 bnf(B.b2, base, 6), base + P.dy2[ds], base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
+                                 base + P.dys[ds], npo, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
