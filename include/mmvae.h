@@ -138,6 +138,28 @@ MMVAE_API int mmvae_conv2d_dgrad(int dtype, int transposed, const void* dy, cons
 MMVAE_API int mmvae_conv2d_wgrad(int dtype, int transposed, const void* x, const void* dy, float* dweight, int N, int H, int W, int Cin,
                        int Cout, int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu,
                        void* stream);
+/* ---- last up-block + tail conv, one output plane (decoder.uplayerN -> decoder.conv2, reference model.py:86-88,193) ----
+ * y2, ys: the two branch outputs [N,H,W,16] of `dtype` (BatchNorm not yet applied); (s2,b2), (ss,bs): per-channel f32
+ * scale/shift of their BatchNorms; the block output is x = relu(y2*s2+b2 + ys*ss+bs).  weight f32 (1,16,3,3), bias f32 (1).
+ * H, W: W a power of two <= 128 (bf16) / 64 (f32), H*W a multiple of that bound; other shapes return MMVAE_ERR_UNSUPPORTED.
+ *
+ * mmvae_tail_join_fwd: r_raw [N,1,H,W] f32 = conv2d(x, weight, bias, padding=1) without storing x.
+ *   stats (nullable): per-image (sum, sumsq) of r_raw, [N][2]; returns N. */
+MMVAE_API int mmvae_tail_join_fwd(int dtype, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
+                        const float* weight, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* stream);
+/* mmvae_tail_join_bwd_reduce: with g = conv_transpose2d(d_raw, weight, padding=1) masked by x > 0 (never stored), writes per-block
+ *   partial sums partials[rows][3][16] = (sum g, sum g*y2, sum g*ys) and, when wpartials != NULL, the tail conv's weight-gradient
+ *   partials wpartials[rows][16][9] (sum over pixels of x[ci] * d_raw[h+1-kh, w+1-kw]); returns rows (<= 1024).
+ *   d_raw [N,out_planes,H,W] f32, weight (out_planes,16,3,3); wpartials needs out_planes == 1. */
+MMVAE_API int mmvae_tail_join_bwd_reduce(int dtype, const float* d_raw, const float* weight, int out_planes, const void* y2, const float* s2,
+                               const float* b2, const void* ys, const float* ss, const float* bs, float* partials, float* wpartials,
+                               int N, int H, int W, void* stream);
+/* mmvae_tail_join_bwd_apply: dy2 = A2*g + B2*y2 + C2, dys = As*g + Bs*ys + Cs with the same masked g and per-channel f32
+ *   coefficient vectors (the BatchNorm-backward affine forms); dy2, dys [N,H,W,16] of `dtype`. */
+MMVAE_API int mmvae_tail_join_bwd_apply(int dtype, const float* d_raw, const float* weight, int out_planes, const void* y2, const float* s2,
+                              const float* b2, const void* ys, const float* ss, const float* bs, const float* A2, const float* B2,
+                              const float* C2, const float* As, const float* Bs, const float* Cs, void* dy2, void* dys, int N, int H, int W,
+                              void* stream);
 /* f32 <-> dtype element conversion (n elements) */
 MMVAE_API int mmvae_convert(int dtype_in, int dtype_out, const void* in, void* out, int64_t n, void* stream);
 

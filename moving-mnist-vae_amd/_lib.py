@@ -45,6 +45,9 @@ PROTOTYPES = {
     "mmvae_conv2d_fwd": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "mmvae_conv2d_dgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "mmvae_conv2d_wgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "mmvae_tail_join_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "mmvae_tail_join_bwd_reduce": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "mmvae_tail_join_bwd_apply": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_convert": (c_int, [c_int, c_int, P, P, c_int64, P]),
 }
 

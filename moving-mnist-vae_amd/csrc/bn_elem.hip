@@ -437,6 +437,11 @@ struct TailG { const float* d_raw; const float* w; int OC, H, W, wshift; int nti
 template <typename T> struct TailW;
 template <> struct TailW<float> {
   float v[9][4];
+  // the LDS form of the same table: word j of (tap t, channel group c0/4)
+  __device__ static __forceinline__ uint32_t word(const float* w, int c0, int t, int j) { return __float_as_uint(w[(c0 + j) * 9 + t]); }
+  __device__ static __forceinline__ void fma_words(const uint4& q, float d, float (&g)[4]) {
+    g[0] += d * __uint_as_float(q.x); g[1] += d * __uint_as_float(q.y); g[2] += d * __uint_as_float(q.z); g[3] += d * __uint_as_float(q.w);
+  }
   __device__ __forceinline__ void load(const float* w, int c0) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -447,9 +452,26 @@ template <> struct TailW<float> {
 #pragma unroll
     for (int j = 0; j < 4; ++j) g[j] += d * v[t][j];
   }
+  __device__ __forceinline__ float dot(int t, const float (&x)[4]) const {
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r += x[j] * v[t][j];
+    return r;
+  }
 };
 template <> struct TailW<bf16_t> {
   uint32_t v[9][4];
+  __device__ static __forceinline__ uint32_t word(const float* w, int c0, int t, int j) {
+    return pack2_bf16(w[(c0 + 2 * j) * 9 + t], w[(c0 + 2 * j + 1) * 9 + t]);
+  }
+  __device__ static __forceinline__ void fma_words(const uint4& q, float d, float (&g)[8]) {
+    const uint32_t pw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      g[2 * j] += d * __uint_as_float(pw[j] << 16);
+      g[2 * j + 1] += d * __uint_as_float(pw[j] & 0xffff0000u);
+    }
+  }
   __device__ __forceinline__ void load(const float* w, int c0) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -465,15 +487,30 @@ template <> struct TailW<bf16_t> {
       g[2 * j + 1] += d * __uint_as_float(pw & 0xffff0000u);
     }
   }
+  __device__ __forceinline__ float dot(int t, const float (&x)[8]) const {
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t pw = v[t][j];
+      asm volatile("" : "+v"(pw));
+      r += x[2 * j] * __uint_as_float(pw << 16);
+      r += x[2 * j + 1] * __uint_as_float(pw & 0xffff0000u);
+    }
+    return r;
+  }
 };
 
-template <typename T, bool OC1, bool APPLY>
-__global__ __launch_bounds__(256, OC1 ? 3 : 2) void tail_join_bwd_kernel(TailG tg, const float* __restrict__ ms, const float* __restrict__ mb,
+// WG (reduce pass, OC == 1 only): also accumulates the tail conv's weight gradient dW[ci][tap] = sum x[ci] * d_raw[tap] with the
+// joined activation x = max(bn(y0) + bn(y1), 0) it has in registers anyway -> wpartials[block][144], tail_wgrad_finalize_kernel.
+template <typename T, bool OC1, bool APPLY, bool WG = false>
+__global__ __launch_bounds__(256, (OC1 && !WG) ? 3 : 2) void tail_join_bwd_kernel(TailG tg, const float* __restrict__ ms, const float* __restrict__ mb,
                                                             const float* __restrict__ ms1, const float* __restrict__ mb1,
                                                             const T* __restrict__ y0, const float* __restrict__ A0, const float* __restrict__ B0,
                                                             const float* __restrict__ C0, T* __restrict__ dy0, const T* __restrict__ y1,
                                                             const float* __restrict__ A1, const float* __restrict__ B1,
-                                                            const float* __restrict__ C1, T* __restrict__ dy1, float* __restrict__ partials) {
+                                                            const float* __restrict__ C1, T* __restrict__ dy1, float* __restrict__ partials,
+                                                            float* __restrict__ wpartials) {
+  static_assert(!WG || (OC1 && !APPLY), "the fused weight gradient rides on the one-plane reduce pass");
   constexpr int VE = Elem<T>::kVec;
   constexpr int CV = 16 / VE, PT = 256 / CV;
   extern __shared__ float smem[];
@@ -486,24 +523,34 @@ __global__ __launch_bounds__(256, OC1 ? 3 : 2) void tail_join_bwd_kernel(TailG t
   const int pr = p >> tg.wshift, pc = p & (W - 1);
   for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;     // halo columns stay zero for the kernel's lifetime
   TailW<T> wr;
-  if (OC1) wr.load(tg.w, cg * VE);
+  if (OC1 && WG) {                                   // register budget goes to the 9 x VE weight-gradient accumulators: table in LDS
+    uint32_t* sWq = reinterpret_cast<uint32_t*>(sW);
+    for (int i = tid; i < 9 * CV * 4; i += 256) sWq[i] = TailW<T>::word(tg.w, ((i >> 2) % CV) * VE, i / (CV * 4), i & 3);
+  } else if (OC1) wr.load(tg.w, cg * VE);
   else
     for (int i = tid; i < OC * 144; i += 256) {      // w[oc][ci][tap] -> sW[oc][tap][ci]
       const int oc = i / 144, rem = i - oc * 144, ci = rem / 9, t = rem - ci * 9;
-      sW[(oc * 9 + t) * 16 + ci] = tg.w[i];
+      float wv = tg.w[i];
+      if (VE == 8) wv = bf16_bits_to_f32(f32_to_bf16_bits(wv));      // the rounding the one-plane table (and the MFMA dgrad) applies
+      sW[(oc * 9 + t) * 16 + ci] = wv;
     }
   float msc[VE], msh[VE], msc1[VE], msh1[VE];
 #pragma unroll
   for (int j = 0; j < VE; ++j) { const int ch = cg * VE + j; msc[j] = ms[ch]; msh[j] = mb[ch]; msc1[j] = ms1[ch]; msh1[j] = mb1[ch]; }
   float a0[VE], b0[VE];
   float acc[3][VE];
-  float* sC = sW + (OC1 ? 0 : OC * 144);            // [4][16] C0, C1, A1, B1 (APPLY: keeps the kernel under 168 VGPRs)
+  float* sC = sW + (OC1 ? (WG ? 9 * CV * 4 : 0) : OC * 144);            // [4][16] C0, C1, A1, B1 (APPLY: keeps the kernel under 168 VGPRs)
 #pragma unroll
   for (int j = 0; j < VE; ++j) {
     const int ch = cg * VE + j;
     if (APPLY) { a0[j] = A0[ch]; b0[j] = B0[ch]; }
     else { acc[0][j] = 0.f; acc[1][j] = 0.f; acc[2][j] = 0.f; }
   }
+  float wacc[WG ? 9 : 1][VE];
+#pragma unroll
+  for (int t = 0; t < (WG ? 9 : 1); ++t)
+#pragma unroll
+    for (int j = 0; j < VE; ++j) wacc[t][j] = 0.f;
   if (APPLY && tid < 64) sC[tid] = (tid < 16 ? C0 : (tid < 32 ? C1 : (tid < 48 ? A1 : B1)))[tid & 15];
   __syncthreads();
   const int stage = rows * W;                        // d_raw elements per plane per tile (<= 3 * PT = 2 per thread)
@@ -553,11 +600,24 @@ __global__ __launch_bounds__(256, OC1 ? 3 : 2) void tail_join_bwd_kernel(TailG t
     float g[VE];
 #pragma unroll
     for (int j = 0; j < VE; ++j) g[j] = 0.f;
+    float xj[VE];
     if (OC1) {
+      if (WG) {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) xj[j] = fmaxf((f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]), 0.f);
+      }
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) wr.fma(kh * 3 + kw, sT[(pr + 2 - kh) * pitch + pc + 2 - kw], g);
+        for (int kw = 0; kw < 3; ++kw) {
+          const float d = sT[(pr + 2 - kh) * pitch + pc + 2 - kw];
+          if (WG) TailW<T>::fma_words(reinterpret_cast<const uint4*>(sW)[(kh * 3 + kw) * CV + cg], d, g);
+          else wr.fma(kh * 3 + kw, d, g);
+          if (WG) {
+#pragma unroll
+            for (int j = 0; j < VE; ++j) wacc[kh * 3 + kw][j] += d * xj[j];
+          }
+        }
     } else {
       for (int oc = 0; oc < OC; ++oc)
 #pragma unroll
@@ -588,7 +648,7 @@ __global__ __launch_bounds__(256, OC1 ? 3 : 2) void tail_join_bwd_kernel(TailG t
     } else {
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
-        const float x = (f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]);
+        const float x = WG ? xj[j] : (f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]);     // max(x, 0) > 0 <=> x > 0
         const float gg = x > 0.f ? g[j] : 0.f;
         acc[0][j] += gg; acc[1][j] += gg * f0[j]; acc[2][j] += gg * f1[j];
       }
@@ -597,6 +657,29 @@ __global__ __launch_bounds__(256, OC1 ? 3 : 2) void tail_join_bwd_kernel(TailG t
   if (!APPLY) {
     __syncthreads();
     block_channel_reduce<3, VE>(acc, CV, 16, sC, partials + (long)blockIdx.x * 3 * 16);
+  }
+  if (WG) {
+    // lanes with equal (lane % CV) share channels: butterfly over the other lane bits, then the four waves through LDS
+    __syncthreads();
+    float* sR = sC;                                  // [4 waves][CV][9 * VE]
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < VE; ++j) {
+        float v = wacc[t][j];
+#pragma unroll
+        for (int m = CV; m < 64; m <<= 1) v += __shfl_xor(v, m);
+        if (lane < CV) sR[(wv * CV + lane) * 9 * VE + t * VE + j] = v;
+      }
+    __syncthreads();
+    if (tid < 144) {
+      const int ci = tid / 9, t = tid - ci * 9, cgo = ci / VE, j = ci - cgo * VE;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += sR[(w * CV + cgo) * 9 * VE + t * VE + j];
+      wpartials[(long)blockIdx.x * 144 + tid] = v;
+    }
   }
 }
 
@@ -611,7 +694,9 @@ bool tail_join_fusable(int dt, int OC, int N, int H, int W) {
 template <bool APPLY>
 static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                             const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
-                            const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, float* partials, hipStream_t s) {
+                            const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, float* partials, float* wpartials,
+                            hipStream_t s) {
+  if (wpartials && (APPLY || OC != 1)) { set_error("tail_join_bwd: fused wgrad needs the one-plane reduce pass"); return MMVAE_ERR_UNSUPPORTED; }
   if (!tail_join_fusable(dt, OC, N, H, W)) { set_error("tail_join_bwd: OC=%d H=%d W=%d not supported", OC, H, W); return MMVAE_ERR_UNSUPPORTED; }
   const int VE = dt == DT_F32 ? 4 : 8, cv = 16 / VE, pt = 256 / cv;
   int wshift = 0;
@@ -620,27 +705,152 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
   int blocks = ntiles < (APPLY ? kElemMaxBlocks : 1024) ? ntiles : (APPLY ? kElemMaxBlocks : 1024);
   const TailG tg{d_raw, w, OC, H, W, wshift, ntiles};
   const int tile_floats = OC * (pt / W + 2) * (W + 2);
-  const size_t sm = ((size_t)2 * tile_floats + (OC == 1 ? 0 : OC * 144) + (APPLY ? 64 : 256 * 3 * VE)) * sizeof(float);
-#define MMVAE_LAUNCH(T, OC1) hipLaunchKernelGGL((tail_join_bwd_kernel<T, OC1, APPLY>), dim3(blocks), dim3(256), sm, s, tg, ms, mb, ms1, mb1, \
-    (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, partials)
-  if (dt == DT_F32) { if (OC == 1) MMVAE_LAUNCH(float, true); else MMVAE_LAUNCH(float, false); }
-  else { if (OC == 1) MMVAE_LAUNCH(bf16_t, true); else MMVAE_LAUNCH(bf16_t, false); }
+  const size_t sm = ((size_t)2 * tile_floats + (OC == 1 ? (wpartials ? 9 * cv * 4 : 0) : OC * 144) + (APPLY ? 64 : 256 * 3 * VE)) * sizeof(float);
+#define MMVAE_LAUNCH(T, OC1, WG) hipLaunchKernelGGL((tail_join_bwd_kernel<T, OC1, APPLY, WG>), dim3(blocks), dim3(256), sm, s, tg, ms, mb, ms1, mb1, \
+    (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, partials, wpartials)
+  if constexpr (!APPLY) {
+    if (wpartials) { if (dt == DT_F32) MMVAE_LAUNCH(float, true, true); else MMVAE_LAUNCH(bf16_t, true, true); }
+  }
+  if (!wpartials) {
+    if (dt == DT_F32) { if (OC == 1) MMVAE_LAUNCH(float, true, false); else MMVAE_LAUNCH(float, false, false); }
+    else { if (OC == 1) MMVAE_LAUNCH(bf16_t, true, false); else MMVAE_LAUNCH(bf16_t, false, false); }
+  }
 #undef MMVAE_LAUNCH
   const int rc = check_launch(APPLY ? "tail_join_bwd_apply" : "tail_join_bwd_reduce");
   return rc ? rc : blocks;
 }
 
+// wpartials != NULL (OC == 1): the pass also leaves the tail conv's weight-gradient partials [blocks][144] there; finish with
+// launch_tail_wgrad_finalize(wpartials, <returned block count>, dW).
 int launch_tail_join_bwd_reduce(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
-                                const float* ms1, const float* mb1, const void* y0, const void* y1, float* partials, hipStream_t s) {
+                                const float* ms1, const float* mb1, const void* y0, const void* y1, float* partials, hipStream_t s,
+                                float* wpartials) {
   return launch_tail_join<false>(dt, d_raw, w, OC, N, H, W, ms, mb, ms1, mb1, y0, nullptr, nullptr, nullptr, nullptr, y1, nullptr, nullptr, nullptr,
-                                 nullptr, partials, s);
+                                 nullptr, partials, wpartials, s);
 }
 
 int launch_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                                const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
                                const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, hipStream_t s) {
-  const int rc = launch_tail_join<true>(dt, d_raw, w, OC, N, H, W, ms, mb, ms1, mb1, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, nullptr, s);
+  const int rc = launch_tail_join<true>(dt, d_raw, w, OC, N, H, W, ms, mb, ms1, mb1, y0, A0, B0, C0, dy0, y1, A1, B1, C1, dy1, nullptr, nullptr, s);
   return rc < 0 ? rc : MMVAE_OK;
+}
+
+// ---------------------------------------------------------------- last up-block: residual join fused with the tail conv (forward)
+// r_raw[n,h,w] = bias + sum_{ci,kh,kw} x[n,h+kh-1,w+kw-1,ci] * w[ci][kh][kw],  x = relu(bn(y2) + bn(ys))   (model.py:193, one plane)
+// The joined activation x (671 MB at N = 5120) is never written: one block walks one image top to bottom, RP = PT/W rows per
+// pass.  Each thread turns its 16-byte vector of x into 9 per-tap partial dot products, the CV lanes of a pixel combine them
+// by shuffle and park them in a 3-pass (4 when RP = 1) LDS ring S[tap][row][col]; an output pixel is then the sum of 9 ring entries.  Every
+// input row is read exactly once (2 x 671 MB in, 84 MB out, against 4 x 671 MB for join + conv).  One barrier per pass: pass
+// k+1 overwrites the ring rows of pass k-2, whose last readers (the outputs of pass k-1) are behind barrier k.
+// Per-block (sum, sum of squares) of r_raw go to stats[block][2] for the output BatchNorm.
+struct TailFwd { const float* w; const float* bias; float* r_raw; float* stats; int H, W, wshift; };
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void tail_join_fwd_kernel(TailFwd a, const T* __restrict__ y0, const float* __restrict__ ms,
+                                                               const float* __restrict__ mb, const T* __restrict__ y1,
+                                                               const float* __restrict__ ms1, const float* __restrict__ mb1) {
+  constexpr int VE = Elem<T>::kVec;
+  constexpr int CV = 16 / VE, PT = 256 / CV;
+  extern __shared__ float smem[];
+  const int W = a.W, H = a.H;
+  const int RP = PT >> a.wshift, NRING = RP >= 2 ? 3 : 4, RR = NRING * RP, pitch = W + 2;   // outputs reach 2 rows back: 1 pass, or 2 when RP = 1
+  float* sS = smem;                                  // [9][RR][pitch]
+  const int tid = threadIdx.x, cg = tid % CV, p = tid / CV;
+  const int pr = p >> a.wshift, pc = p & (W - 1);
+  for (int i = tid; i < 9 * RR * pitch; i += 256) sS[i] = 0.f;      // halo columns stay zero
+  TailW<T> wr;
+  wr.load(a.w, cg * VE);
+  float msc[VE], msh[VE], msc1[VE], msh1[VE];
+#pragma unroll
+  for (int j = 0; j < VE; ++j) { const int ch = cg * VE + j; msc[j] = ms[ch]; msh[j] = mb[ch]; msc1[j] = ms1[ch]; msh1[j] = mb1[ch]; }
+  const float bias = a.bias[0];
+  const long n = blockIdx.x;
+  const Vec16* v0 = reinterpret_cast<const Vec16*>(y0) + n * H * W * CV + tid;
+  const Vec16* v1 = reinterpret_cast<const Vec16*>(y1) + n * H * W * CV + tid;
+  float* out = a.r_raw + n * H * W;
+  const int npass = H / RP;
+  Vec16 q0 = v0[0], q1 = v1[0];
+  float s1 = 0.f, s2 = 0.f;
+  __syncthreads();
+  int k3 = 0;                                        // k mod NRING
+  for (int k = 0; k <= npass; ++k) {
+    const int slot = k3 * RP + pr;
+    float sp[9];
+    if (k < npass) {
+      float f0[VE], f1[VE], x[VE];
+      Elem<T>::unpack(q0, f0);
+      Elem<T>::unpack(q1, f1);
+      if (k + 1 < npass) { q0 = v0[(long)(k + 1) * 256]; q1 = v1[(long)(k + 1) * 256]; }
+#pragma unroll
+      for (int j = 0; j < VE; ++j) x[j] = fmaxf((f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]), 0.f);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float v = wr.dot(t, x);
+#pragma unroll
+        for (int m = 1; m < CV; m <<= 1) v += __shfl_xor(v, m);
+        sp[t] = v;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) sp[t] = 0.f;       // the row below the image
+    }
+    if (cg == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) sS[(t * RR + slot) * pitch + pc + 1] = sp[t];
+    }
+    __syncthreads();
+    if (tid < PT) {
+      const int ro = tid >> a.wshift, col = tid & (W - 1);
+      const int h = k * RP - 1 + ro;
+      if (h >= 0 && h < H) {
+        float v = bias;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hh = h + kh - 1;
+          int sl = k3 * RP + ro + kh - 2 + RR;       // ring slot of row hh
+          if (sl >= RR) sl -= RR;
+          if (hh >= 0 && hh < H) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) v += sS[((kh * 3 + kw) * RR + sl) * pitch + col + kw];
+          }
+        }
+        out[h * W + col] = v;
+        s1 += v; s2 += v * v;
+      }
+    }
+    k3 = k3 == NRING - 1 ? 0 : k3 + 1;
+  }
+  if (a.stats) {
+    __shared__ float sRed[2][4];
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((tid & 63) == 0) { sRed[0][tid >> 6] = s1; sRed[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid < 2) a.stats[(long)blockIdx.x * 2 + tid] = (sRed[tid][0] + sRed[tid][1]) + (sRed[tid][2] + sRed[tid][3]);
+  }
+}
+
+// Whether the image walk above covers an H x W output with element type dt (one output plane only).
+bool tail_fwd_fusable(int dt, int OC, int N, int H, int W) {
+  const int cv = dt == DT_F32 ? 4 : 2, pt = 256 / cv;
+  if (OC != 1 || W < 1 || (W & (W - 1)) || W > pt) return false;
+  return H % (pt / W) == 0 && N >= 1;
+}
+
+// returns the number of stats partials (= N) or a negative error
+int launch_tail_join_fwd(int dt, const void* y0, const float* ms, const float* mb, const void* y1, const float* ms1, const float* mb1,
+                         const float* w, const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s) {
+  if (!tail_fwd_fusable(dt, 1, N, H, W)) { set_error("tail_join_fwd: H=%d W=%d not supported", H, W); return MMVAE_ERR_UNSUPPORTED; }
+  const int cv = dt == DT_F32 ? 4 : 2, pt = 256 / cv;
+  int wshift = 0;
+  while ((1 << wshift) < W) ++wshift;
+  const TailFwd a{w, bias, r_raw, stats, H, W, wshift};
+  const int rp = pt / W;
+  const size_t sm = (size_t)9 * (rp >= 2 ? 3 : 4) * rp * (W + 2) * sizeof(float);
+  if (dt == DT_F32) hipLaunchKernelGGL((tail_join_fwd_kernel<float>), dim3(N), dim3(256), sm, s, a, (const float*)y0, ms, mb, (const float*)y1, ms1, mb1);
+  else hipLaunchKernelGGL((tail_join_fwd_kernel<bf16_t>), dim3(N), dim3(256), sm, s, a, (const bf16_t*)y0, ms, mb, (const bf16_t*)y1, ms1, mb1);
+  const int rc = check_launch("tail_join_fwd");
+  return rc ? rc : N;
 }
 
 // ---------------------------------------------------------------- tail conv weight gradient, one output plane
@@ -648,8 +858,12 @@ int launch_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int O
 // backward above, with 9 x VE accumulators per thread instead of an MFMA tile (a 16 x 9 result over 21 M pixels is a
 // reduction, not a GEMM: the MFMA wgrad spends its time transposing operands and reaches 1.4 TB/s on it).
 // Deterministic: per-block partials [block][144] in (ci, tap) order, summed by tail_wgrad_finalize_kernel.
-template <typename T>
-__global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T* __restrict__ x, float* __restrict__ partials) {
+// JOIN: x is not stored (fused forward above) and is recomputed as relu(bn(x) + bn(x1)) from the two branch outputs.
+template <typename T, bool JOIN>
+__global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T* __restrict__ x, const T* __restrict__ x1,
+                                                              const float* __restrict__ ms, const float* __restrict__ mb,
+                                                              const float* __restrict__ ms1, const float* __restrict__ mb1,
+                                                              float* __restrict__ partials) {
   constexpr int VE = Elem<T>::kVec;
   constexpr int CV = 16 / VE, PT = 256 / CV;
   extern __shared__ float smem[];
@@ -661,6 +875,11 @@ __global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T*
   const int tid = threadIdx.x, p = tid / CV;
   const int pr = p >> tg.wshift, pc = p & (W - 1);
   for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;
+  float msc[VE], msh[VE], msc1[VE], msh1[VE];
+  if (JOIN) {
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { const int ch = (tid % CV) * VE + j; msc[j] = ms[ch]; msh[j] = mb[ch]; msc1[j] = ms1[ch]; msh1[j] = mb1[ch]; }
+  }
   float acc[9][VE];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -669,7 +888,7 @@ __global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T*
   __syncthreads();
   const int stage = rows * W;
   const int G = gridDim.x;
-  Vec16 q[2];                                        // x vectors of the next two tiles
+  Vec16 q[2], r[2];                                  // x (and x1) vectors of the next two tiles
   float dpre[2] = {0.f, 0.f};
   auto fetch_d = [&](int t) {
     const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;      // uniform
@@ -681,8 +900,12 @@ __global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T*
     }
   };
   const int t0 = blockIdx.x;
-  if (t0 < tg.ntiles) { q[0] = reinterpret_cast<const Vec16*>(x)[(long)t0 * 256 + tid]; fetch_d(t0); }
-  if (t0 + G < tg.ntiles) q[1] = reinterpret_cast<const Vec16*>(x)[(long)(t0 + G) * 256 + tid];
+  auto fetch_x = [&](int t, int slot) {
+    q[slot] = reinterpret_cast<const Vec16*>(x)[(long)t * 256 + tid];
+    if (JOIN) r[slot] = reinterpret_cast<const Vec16*>(x1)[(long)t * 256 + tid];
+  };
+  if (t0 < tg.ntiles) { fetch_x(t0, 0); fetch_d(t0); }
+  if (t0 + G < tg.ntiles) fetch_x(t0 + G, 1);
   int buf = 0;
   for (int t = t0; t < tg.ntiles; t += G, buf ^= 1) {
     float* sT = sD + buf * tile_floats;
@@ -693,9 +916,16 @@ __global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T*
     }
     float f[VE];
     Elem<T>::unpack(q[0], f);
+    if (JOIN) {
+      float f1[VE];
+      Elem<T>::unpack(r[0], f1);
+#pragma unroll
+      for (int j = 0; j < VE; ++j) f[j] = fmaxf((f[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]), 0.f);
+      r[0] = r[1];
+    }
     q[0] = q[1];
     if (t + G < tg.ntiles) fetch_d(t + G);
-    if (t + 2 * G < tg.ntiles) q[1] = reinterpret_cast<const Vec16*>(x)[(long)(t + 2 * G) * 256 + tid];
+    if (t + 2 * G < tg.ntiles) fetch_x(t + 2 * G, 1);
     __syncthreads();
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
@@ -734,9 +964,16 @@ __global__ __launch_bounds__(64) void tail_wgrad_finalize_kernel(const float* __
   if (threadIdx.x == 0) dW[blockIdx.x] += (float)s;
 }
 
+int launch_tail_wgrad_finalize(const float* wpartials, int nparts, float* dW, hipStream_t s) {
+  hipLaunchKernelGGL(tail_wgrad_finalize_kernel, dim3(144), dim3(64), 0, s, wpartials, nparts, dW);
+  return check_launch("tail_wgrad_finalize");
+}
+
 // x = the tail conv's input (NHWC, 16 channels), d_raw = its output gradient (one f32 plane); dW[16][3][3] is accumulated into.
 // scratch: at least 1024 * 144 floats.  The geometry must pass tail_join_fusable(dt, 1, N, H, W).
-int launch_tail_wgrad_tile(int dt, const void* x, const float* d_raw, float* dW, float* scratch, int N, int H, int W, hipStream_t s) {
+// x1 != NULL: x, x1 are the two branch outputs and (ms, mb), (ms1, mb1) their BatchNorm scale/shift (the joined input is recomputed).
+int launch_tail_wgrad_tile(int dt, const void* x, const void* x1, const float* ms, const float* mb, const float* ms1, const float* mb1,
+                           const float* d_raw, float* dW, float* scratch, int N, int H, int W, hipStream_t s) {
   if (!tail_join_fusable(dt, 1, N, H, W)) { set_error("tail_wgrad_tile: H=%d W=%d not supported", H, W); return MMVAE_ERR_UNSUPPORTED; }
   const int VE = dt == DT_F32 ? 4 : 8, cv = 16 / VE, pt = 256 / cv;
   int wshift = 0;
@@ -745,8 +982,11 @@ int launch_tail_wgrad_tile(int dt, const void* x, const float* d_raw, float* dW,
   const int blocks = ntiles < 1024 ? ntiles : 1024;
   const TailG tg{d_raw, nullptr, 1, H, W, wshift, ntiles};
   const size_t sm = ((size_t)2 * (pt / W + 2) * (W + 2) + 4 * cv * 9 * VE) * sizeof(float);
-  if (dt == DT_F32) hipLaunchKernelGGL((tail_wgrad_tile_kernel<float>), dim3(blocks), dim3(256), sm, s, tg, (const float*)x, scratch);
-  else hipLaunchKernelGGL((tail_wgrad_tile_kernel<bf16_t>), dim3(blocks), dim3(256), sm, s, tg, (const bf16_t*)x, scratch);
+#define MMVAE_LAUNCH(T, JOIN) hipLaunchKernelGGL((tail_wgrad_tile_kernel<T, JOIN>), dim3(blocks), dim3(256), sm, s, tg, (const T*)x, (const T*)x1, \
+    ms, mb, ms1, mb1, scratch)
+  if (dt == DT_F32) { if (x1) MMVAE_LAUNCH(float, true); else MMVAE_LAUNCH(float, false); }
+  else { if (x1) MMVAE_LAUNCH(bf16_t, true); else MMVAE_LAUNCH(bf16_t, false); }
+#undef MMVAE_LAUNCH
   hipLaunchKernelGGL(tail_wgrad_finalize_kernel, dim3(144), dim3(64), 0, s, scratch, blocks, dW);
   return check_launch("tail_wgrad_tile");
 }

@@ -182,6 +182,20 @@ int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, fl
   if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st), scratch[dev]);
   return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), scratch[dev]);
 }
+int mmvae_tail_join_fwd(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
+                        const float* w, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* st) {
+  return launch_tail_join_fwd(dt, y2, s2, b2, ys, ss, bs, w, bias, r_raw, stats, N, H, W, S(st));
+}
+int mmvae_tail_join_bwd_reduce(int dt, const float* d_raw, const float* w, int oc, const void* y2, const float* s2, const float* b2,
+                               const void* ys, const float* ss, const float* bs, float* partials, float* wpartials, int N, int H, int W,
+                               void* st) {
+  return launch_tail_join_bwd_reduce(dt, d_raw, w, oc, N, H, W, s2, b2, ss, bs, y2, ys, partials, S(st), wpartials);
+}
+int mmvae_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int oc, const void* y2, const float* s2, const float* b2,
+                              const void* ys, const float* ss, const float* bs, const float* A2, const float* B2, const float* C2,
+                              const float* As, const float* Bs, const float* Cs, void* dy2, void* dys, int N, int H, int W, void* st) {
+  return launch_tail_join_bwd_apply(dt, d_raw, w, oc, N, H, W, s2, b2, ss, bs, y2, A2, B2, C2, dy2, ys, As, Bs, Cs, dys, S(st));
+}
 int mmvae_convert(int di, int dout, const void* in, void* out, int64_t n, void* st) { return launch_convert(di, dout, in, out, (long)n, S(st)); }
 
 }  // extern "C"

@@ -205,11 +205,18 @@ int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* 
 // last up-block: residual-join backward with the incoming gradient recomputed from the reconstruction gradient (bn_elem.hip)
 bool tail_join_fusable(int dt, int OC, int N, int H, int W);
 int launch_tail_join_bwd_reduce(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
-                                const float* ms1, const float* mb1, const void* y0, const void* y1, float* partials, hipStream_t s);
+                                const float* ms1, const float* mb1, const void* y0, const void* y1, float* partials, hipStream_t s,
+                                float* wpartials = nullptr);
+int launch_tail_wgrad_finalize(const float* wpartials, int nparts, float* dW, hipStream_t s);
 int launch_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                                const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
                                const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, hipStream_t s);
-int launch_tail_wgrad_tile(int dt, const void* x, const float* d_raw, float* dW, float* scratch, int N, int H, int W, hipStream_t s);
+int launch_tail_wgrad_tile(int dt, const void* x, const void* x1, const float* ms, const float* mb, const float* ms1, const float* mb1,
+                           const float* d_raw, float* dW, float* scratch, int N, int H, int W, hipStream_t s);
+// last up-block forward: residual join + tail conv in one pass, the joined activation is not stored (bn_elem.hip)
+bool tail_fwd_fusable(int dt, int OC, int N, int H, int W);
+int launch_tail_join_fwd(int dt, const void* y0, const float* ms, const float* mb, const void* y1, const float* ms1, const float* mb1,
+                         const float* w, const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s);
 // NCHW f32 variants for the output BatchNorm (decoder.bn2): recon = raw*scale+shift ; backward pieces
 int launch_affine_nchw(const float* raw, const float* scale, const float* shift, float* out, int N, int C, int HW, hipStream_t s);
 int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s);

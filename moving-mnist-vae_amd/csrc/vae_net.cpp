@@ -213,6 +213,14 @@ int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const f
   return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_);
 }
 
+bool Net::tail_fwd_fused() const {
+  static const bool env = [] { const char* e = getenv("MMVAE_TAIL_FWD_FUSED"); return !(e && e[0] == '0'); }();
+  static const bool bwd_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
+  // N does not enter the geometry checks beyond the tile count limit, which the plan's maximum batch already satisfies
+  return env && bwd_env && nup >= 1 && dec[nup - 1].C == 16 && tail_fwd_fusable(dt(), cfg.out_ch, 1, Sd, Sd) &&
+         tail_join_fusable(dt(), cfg.out_ch, 1, Sd, Sd);
+}
+
 int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s,
                   long part_off) {
   BnFinalizeArgs a;
@@ -550,6 +558,7 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
     if (side_fwd) MM_TRY(side_join(s));
+    if (i == nup - 1 && tail_fwd_fused()) break;     // the join of the last block happens inside the tail conv kernel
     MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2),
                            bnf(B.bs, base, 3), base + B.out, (long)N * B.Hout * B.Wout, B.C, s));
     xin = base + B.out; xs = xb = nullptr;
@@ -557,7 +566,13 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   // tail conv (+bias) and the output BatchNorm (model.py:193)
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
   static const bool tail_direct_f = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
-  if (tail_direct_f) {
+  if (tail_fwd_fused()) {
+    const Block& B = dec[nup - 1];
+    np = launch_tail_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
+                              params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
+    MM_TRY(np);
+    if (training) MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
+  } else if (tail_direct_f) {
     MM_TRY(launch_tail_fwd(dt(), xin, params + tail.off, params + tail_bias, r_raw, N, Sd, Sd, cfg.out_ch, s));
     if (training) {
       np = launch_chan_stats_nchw(r_raw, N, cfg.out_ch, Sd * Sd, part, s);
@@ -610,11 +625,24 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   static const bool tail_wgrad_direct = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_DIRECT"); return e && e[0] == '1'; }();
   // one output plane: a tiled VALU reduction (launch_tail_wgrad_tile) beats the MFMA wgrad; MMVAE_TAIL_WGRAD_TILE=0 disables it
   static const bool tail_wgrad_tile_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_TILE"); return !(e && e[0] == '0'); }();
-  if (tail_wgrad_direct) {
+  static const bool tail_fused_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
+  static const bool tail_wg_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_IN_REDUCE"); return !(e && e[0] == '0'); }();
+  const bool tail_fused = tail_fused_env && nup >= 1 && dec[nup - 1].C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
+  // forward did not store the joined activation: the weight gradient recomputes it, inside the join-backward reduce pass (below)
+  // or, MMVAE_TAIL_WGRAD_IN_REDUCE=0, in its own kernel on the side stream
+  const bool tail_wg_in_reduce = tail_fwd_fused() && tail_fused && tail_wg_env;
+  if (tail_wg_in_reduce) {
+  } else if (tail_fwd_fused()) {
+    const Block& B = dec[nup - 1];
+    MM_TRY(side_fork(s));
+    MM_TRY(launch_tail_wgrad_tile(dt(), base + B.y2, base + B.ys, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2), bnf(B.bs, base, 3),
+                                  d_raw, grads + tail.off, wscratch_, N, Sd, Sd, wgrad_stream(s)));
+  } else if (tail_wgrad_direct) {
     MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, nullptr, N, Sd, Sd, cfg.out_ch, s));
   } else if (tail_wgrad_tile_env && cfg.out_ch == 1 && nup >= 1 && tail_join_fusable(dt(), 1, N, Sd, Sd)) {
     MM_TRY(side_fork(s));
-    MM_TRY(launch_tail_wgrad_tile(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, wscratch_, N, Sd, Sd, wgrad_stream(s)));
+    MM_TRY(launch_tail_wgrad_tile(dt(), base + dec[nup - 1].out, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, grads + tail.off, wscratch_,
+                                  N, Sd, Sd, wgrad_stream(s)));
   } else {
     // dW[oc][ci][kh][kw]: P = d_raw (planar f32, out_ch planes staged as 16 zero-padded channels), G = the last up-block's output
     WgradArgs a; std::memset(&a, 0, sizeof(a));
@@ -629,8 +657,6 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   static const bool tail_direct = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
   // The tail conv's input gradient is not materialised: the last up-block's join backward recomputes it from d_raw
   // (launch_tail_join_bwd_*; MMVAE_TAIL_FUSED=0 restores the separate dgrad kernel).
-  static const bool tail_fused_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
-  const bool tail_fused = tail_fused_env && nup >= 1 && dec[nup - 1].C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
   if (tail_fused) {
   } else if (tail_direct) {
     MM_TRY(launch_tail_dgrad(dt(), d_raw, params + tail.off, base + P.g[cur], N, Sd, Sd, cfg.out_ch, s));
@@ -656,10 +682,14 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     const int ds = i & 1;          // dy set of this block (see encoder_bwd)
     if (i + 2 <= nup - 1) MM_TRY(side_wait_mark(i + 2, s));
     const bool from_tail = tail_fused && i == nup - 1;
-    if (from_tail)
+    if (from_tail) {
       np = launch_tail_join_bwd_reduce(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
-                                       bnf(B.bs, base, 3), base + B.y2, base + B.ys, part, s);
-    else
+                                       bnf(B.bs, base, 3), base + B.y2, base + B.ys, part, s, tail_wg_in_reduce ? wscratch_ : nullptr);
+      if (tail_wg_in_reduce && np > 0) {
+        MM_TRY(side_fork(s));
+        MM_TRY(launch_tail_wgrad_finalize(wscratch_, np, grads + tail.off, wgrad_stream(s)));
+      }
+    } else
       np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
                                 bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);

@@ -104,6 +104,9 @@ class Net {
              const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s);
   int run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
                 const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s);
+  // Last up-block forward as one kernel (join + tail conv, the joined activation is never stored); the backward then needs the
+  // recomputing wgrad and the recomputing join backward.  MMVAE_TAIL_FWD_FUSED=0 restores join -> conv.
+  bool tail_fwd_fused() const;
   int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0);
   int bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s);
   float* bnf(const Bn& bn, char* base, int which) const;   // 0 mean 1 istd 2 scale 3 shift 4 A 5 B 6 C

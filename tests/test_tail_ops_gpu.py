@@ -1,0 +1,155 @@
+"""GPU: the fused last-up-block kernels (through the C ABI) against torch CPU fp32 autograd of the unfused graph.
+
+The graph (reference model.py:86-88 residual join, :193 tail conv):
+    x = relu(y2 * s2 + b2 + ys * ss + bs);  r = conv2d(x, w, bias, padding=1)
+  mmvae_tail_join_fwd         r (+ per-image sum / sum of squares) without storing x
+  mmvae_tail_join_bwd_reduce  with g = dL/dx masked by x > 0: sum g, sum g*y2, sum g*ys per channel (+ dL/dw partials)
+  mmvae_tail_join_bwd_apply   dy2 = A2*g + B2*y2 + C2, dys = As*g + Bs*ys + Cs
+
+Tolerances: f32 3e-5 of the output scale.  bf16: the kernels read bf16 y2 / ys and keep x, g in f32, while weights are
+rounded to bf16 for the products that the MFMA path would do in bf16 (g); the reference uses the same rounded inputs and
+weights in fp32, so 1e-2 covers the bf16 output rounding of dy2 / dys (2^-9) with margin; reductions are f32: 2e-4.
+"""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, out_planes)
+SHAPES = [(3, 64, 64, 1), (5, 32, 32, 1), (2, 16, 16, 1), (2, 64, 64, 3), (3, 32, 32, 8), (1100, 8, 8, 1)]
+
+
+def _lib():
+    return importlib.import_module("moving-mnist-vae_amd._lib")
+
+
+def _round(t, dt):
+    return t.to(torch.bfloat16).float() if dt == "bf16" else t
+
+
+def _nhwc(t, dt):
+    x = t.permute(0, 2, 3, 1).contiguous().cuda()
+    return x.to(torch.bfloat16) if dt == "bf16" else x
+
+
+def _case(shape, dt):
+    N, H, W, OC = shape
+    g = torch.Generator().manual_seed(N * 1000 + H + OC)
+    y2 = _round(torch.randn(N, 16, H, W, generator=g), dt)
+    ys = _round(torch.randn(N, 16, H, W, generator=g), dt)
+    s2, ss = torch.rand(16, generator=g) + 0.5, torch.rand(16, generator=g) + 0.5
+    b2, bs = torch.randn(16, generator=g) * 0.3, torch.randn(16, generator=g) * 0.3
+    w = torch.randn(OC, 16, 3, 3, generator=g) / 12.0
+    bias = torch.randn(OC, generator=g)
+    d_raw = torch.randn(N, OC, H, W, generator=g)
+    return y2, ys, s2, b2, ss, bs, w, bias, d_raw
+
+
+def _supported(shape, dt):
+    N, H, W, OC = shape
+    pt = 64 if dt == "f32" else 128
+    return W <= pt and (H * W) % pt == 0
+
+
+def _join(y2, s2, b2, ys, ss, bs):
+    v = lambda t: t.view(1, -1, 1, 1)
+    return F.relu((y2 * v(s2) + v(b2)) + (ys * v(ss) + v(bs)))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[3] == 1], ids=lambda s: "x".join(map(str, s)))
+def test_tail_join_fwd(shape, dt):
+    L = _lib()
+    lib = L.lib()
+    N, H, W, OC = shape
+    y2, ys, s2, b2, ss, bs, w, bias, _ = _case(shape, dt)
+    dti = 0 if dt == "f32" else 1
+    st = torch.cuda.current_stream().cuda_stream
+    y2d, ysd = _nhwc(y2, dt), _nhwc(ys, dt)
+    dev = [t.cuda() for t in (s2, b2, ss, bs, w, bias)]
+    r = torch.full((N, 1, H, W), float("nan"), device="cuda")
+    stats = torch.zeros(N, 2, device="cuda")
+    rc = lib.mmvae_tail_join_fwd(dti, L.ptr(y2d), L.ptr(dev[0]), L.ptr(dev[1]), L.ptr(ysd), L.ptr(dev[2]), L.ptr(dev[3]), L.ptr(dev[4]),
+                                 L.ptr(dev[5]), L.ptr(r), L.ptr(stats), N, H, W, st)
+    pt = 64 if dt == "f32" else 128
+    if W > pt or H % (pt // W):
+        assert rc < 0, "unsupported geometry must be refused, not computed"
+        return
+    assert L.check(rc, "tail_join_fwd") == N
+    torch.cuda.synchronize()
+    ref = F.conv2d(_join(y2, s2, b2, ys, ss, bs), _round(w, dt), bias, padding=1)
+    tol = 3e-5 if dt == "f32" else 2e-4
+    err = ((r.cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert err < tol, (shape, dt, err)
+    sh = stats.cpu()
+    assert torch.allclose(sh[:, 0], ref.sum((1, 2, 3)), rtol=1e-4, atol=1e-3 * H * W ** 0.5)
+    assert torch.allclose(sh[:, 1], (ref ** 2).sum((1, 2, 3)), rtol=2e-4)
+
+
+@pytest.mark.parametrize("wgrad", [False, True])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_tail_join_bwd(shape, dt, wgrad):
+    L = _lib()
+    lib = L.lib()
+    N, H, W, OC = shape
+    if wgrad and OC != 1:
+        pytest.skip("fused weight gradient is the one-plane case")
+    y2, ys, s2, b2, ss, bs, w, bias, d_raw = _case(shape, dt)
+    dti = 0 if dt == "f32" else 1
+    st = torch.cuda.current_stream().cuda_stream
+    y2d, ysd = _nhwc(y2, dt), _nhwc(ys, dt)
+    s2d, b2d, ssd, bsd, wd, drd = [t.cuda() for t in (s2, b2, ss, bs, w, d_raw)]
+    partials = torch.zeros(1024, 3, 16, device="cuda")
+    wpart = torch.zeros(1024, 16, 9, device="cuda") if wgrad else None
+    rows = lib.mmvae_tail_join_bwd_reduce(dti, L.ptr(drd), L.ptr(wd), OC, L.ptr(y2d), L.ptr(s2d), L.ptr(b2d), L.ptr(ysd), L.ptr(ssd),
+                                          L.ptr(bsd), L.ptr(partials), L.ptr(wpart), N, H, W, st)
+    if not _supported(shape, dt):
+        assert rows < 0, "unsupported geometry must be refused, not computed"
+        return
+    rows = L.check(rows, "tail_join_bwd_reduce")
+    assert 1 <= rows <= 1024
+    # reference: autograd through x = join(...), r = conv(x, w)
+    wq = _round(w, dt)
+    x = _join(y2, s2, b2, ys, ss, bs).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wq, None, padding=1).backward(d_raw)
+    g = x.grad * (x.detach() > 0)
+    F.conv2d(x.detach(), wr, None, padding=1).backward(d_raw)
+    sums = partials[:rows].sum(0).cpu()
+    ref = torch.stack([g.sum((0, 2, 3)), (g * y2).sum((0, 2, 3)), (g * ys).sum((0, 2, 3))])
+    scale = torch.stack([g.abs().sum((0, 2, 3)), (g * y2).abs().sum((0, 2, 3)), (g * ys).abs().sum((0, 2, 3))])
+    tol = 3e-5 if dt == "f32" else 2e-4
+    err = ((sums - ref).abs() / scale).max().item()
+    assert err < tol, (shape, dt, "sums", err)
+    if wgrad:
+        dw = wpart[:rows].sum(0).cpu().view(1, 16, 3, 3)
+        err = ((dw - wr.grad).abs().max() / wr.grad.abs().max()).item()
+        assert err < (1e-4 if dt == "f32" else 2e-4), (shape, dt, "wgrad", err)
+    # apply
+    gen = torch.Generator().manual_seed(7)
+    co = [torch.randn(16, generator=gen) for _ in range(6)]
+    cod = [c.cuda() for c in co]
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    dy2 = torch.full((N, H, W, 16), float("nan"), device="cuda", dtype=tdt)
+    dys = torch.full((N, H, W, 16), float("nan"), device="cuda", dtype=tdt)
+    L.check(lib.mmvae_tail_join_bwd_apply(dti, L.ptr(drd), L.ptr(wd), OC, L.ptr(y2d), L.ptr(s2d), L.ptr(b2d), L.ptr(ysd), L.ptr(ssd), L.ptr(bsd),
+                                          L.ptr(cod[0]), L.ptr(cod[1]), L.ptr(cod[2]), L.ptr(cod[3]), L.ptr(cod[4]), L.ptr(cod[5]),
+                                          L.ptr(dy2), L.ptr(dys), N, H, W, st), "tail_join_bwd_apply")
+    torch.cuda.synchronize()
+    v = lambda t: t.view(1, -1, 1, 1)
+    r2 = v(co[0]) * g + v(co[1]) * y2 + v(co[2])
+    rs = v(co[3]) * g + v(co[4]) * ys + v(co[5])
+    tol = 3e-5 if dt == "f32" else 1e-2
+    for got, want in ((dy2, r2), (dys, rs)):
+        err = ((got.float().cpu().permute(0, 3, 1, 2) - want).abs().max() / want.abs().max()).item()
+        assert err < tol, (shape, dt, "apply", err)
