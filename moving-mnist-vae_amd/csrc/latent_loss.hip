@@ -214,65 +214,126 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ x, int n, int d, flo
   if (lane == 0) out[row] = a;
 }
 
+// Persistent MFMA kernel.  The work list holds only the 64 x 64 tiles that count: the symmetric xx / yy sums pair tile row p
+// with row tiles-1-p (tiles+1 upper-triangle entries per pair), xy takes the full square; a block walks the list with stride
+// gridDim.x and issues ONE double atomic at the end (one per tile serialised 12.9 k same-address atomics at N = 5120).
+// The 64 x 64 x d inner products run on the bf16 MFMA with each f32 operand split into hi + lo bf16 halves,
+//   a.b ~= ah.bh + ah.bl + al.bh      (inputs kept to 16 mantissa bits: |error| <= 2^-15 |a||b|, i.e. < 1e-7 of the exponent
+// d2/d^2), 3 x v_mfma_f32_16x16x32_bf16 per 32 k instead of 8 x v_mfma_f32_16x16x4_f32 at a sixteenth of the rate; the squared
+// norms stay exact f32 (row_sqnorm_kernel), so k(a, a) = exp(-(2|a|^2 - 2 a.a)/d^2) stays within the same bound of 1.
+struct MmdEntry { int which, it, jt; bool valid; };
+__device__ __forceinline__ MmdEntry mmd_entry(int e, int tiles, int S) {
+  MmdEntry m;
+  m.valid = true;
+  if (e >= 2 * S) { m.which = 2; e -= 2 * S; m.it = e / tiles; m.jt = e - m.it * tiles; return m; }
+  m.which = e >= S ? 1 : 0;
+  if (m.which) e -= S;
+  const int p = e / (tiles + 1), c = e - p * (tiles + 1);
+  if (c < tiles - p) { m.it = p; m.jt = p + c; }
+  else { m.it = tiles - 1 - p; m.jt = m.it + (c - (tiles - p)); m.valid = m.it != p; }     // odd tile counts: the middle row pairs with itself
+  return m;
+}
+
 __global__ __launch_bounds__(256) void mmd_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ nx, const float* __restrict__ ny, int n, int d,
-                                                           double* out) {
-  __shared__ float sA[64][33];
-  __shared__ float sB[64][33];
-  const int which = blockIdx.z;     // 0: xx, 1: yy, 2: xy
-  const int it = blockIdx.y, jt = blockIdx.x;
-  if (which < 2 && jt < it) return;                 // symmetric: upper triangle of tiles only (uniform per block)
-  const float* A = which == 1 ? y : x;
-  const float* B = which == 0 ? x : y;
-  const float* nA = which == 1 ? ny : nx;
-  const float* nB = which == 0 ? nx : ny;
-  const int i0 = it * 64, j0 = jt * 64;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
+                                                           int tiles, double* out) {
+  constexpr int kPitch = 40;                        // bf16 per row: 32 + 8 pad = 80 B, 16-byte fragment reads hit all banks once
+  __shared__ __attribute__((aligned(16))) uint16_t sT[4][64 * kPitch];      // A hi, A lo, B hi, B lo
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, r = lane & 15;
   const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;   // this wave's 32x32 quadrant
-  f32x4 acc[2][2];
+  const float inv = 1.0f / ((float)d * (float)d);
+  const float nscale = -inv * 1.44269504088896341f;    // exp(-d2 * inv) = exp2(d2 * nscale)
+  const bool vec4 = (d & 3) == 0;
+  const int S = ((tiles + 1) / 2) * (tiles + 1);
+  const int total = 2 * S + tiles * tiles;
+  const int srow = tid >> 3, scol = (tid & 7) * 4;    // staging: rows srow and srow + 32, k columns scol .. scol + 3
+  double sum = 0.0;
+  for (int e = blockIdx.x; e < total; e += gridDim.x) {
+    const MmdEntry m = mmd_entry(e, tiles, S);        // uniform per block
+    if (!m.valid) continue;
+    const float* A = m.which == 1 ? y : x;
+    const float* B = m.which == 0 ? x : y;
+    const float* nA = m.which == 1 ? ny : nx;
+    const float* nB = m.which == 0 ? nx : ny;
+    const int i0 = m.it * 64, j0 = m.jt * 64;
+    f32x4 acc[2][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
-  for (int k0 = 0; k0 < d; k0 += 32) {
-    __syncthreads();
-    for (int v = threadIdx.x; v < 64 * 32; v += 256) {
-      const int rr = v >> 5, kk = v & 31;
-      sA[rr][kk] = (i0 + rr < n && k0 + kk < d) ? A[(long)(i0 + rr) * d + k0 + kk] : 0.f;
-      sB[rr][kk] = (j0 + rr < n && k0 + kk < d) ? B[(long)(j0 + rr) * d + k0 + kk] : 0.f;
-    }
-    __syncthreads();
+      for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
+    for (int k0 = 0; k0 < d; k0 += 32) {
+      float va[2][4], vb[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      float av[2], bv[2];
+      for (int h = 0; h < 2; ++h) {
+        const int rr = srow + 32 * h, kk = k0 + scol;
+        const float* pa = A + (long)(i0 + rr) * d + kk;
+        const float* pb = B + (long)(j0 + rr) * d + kk;
+        if (vec4) {
+          const float4 qa = (kk < d && i0 + rr < n) ? *reinterpret_cast<const float4*>(pa) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 qb = (kk < d && j0 + rr < n) ? *reinterpret_cast<const float4*>(pb) : make_float4(0.f, 0.f, 0.f, 0.f);
+          va[h][0] = qa.x; va[h][1] = qa.y; va[h][2] = qa.z; va[h][3] = qa.w;
+          vb[h][0] = qb.x; vb[h][1] = qb.y; vb[h][2] = qb.z; vb[h][3] = qb.w;
+        } else {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = sA[wi + 16 * a + r][4 * ks + g];
+          for (int c = 0; c < 4; ++c) {
+            va[h][c] = (kk + c < d && i0 + rr < n) ? pa[c] : 0.f;
+            vb[h][c] = (kk + c < d && j0 + rr < n) ? pb[c] : 0.f;
+          }
+        }
+      }
+      __syncthreads();                               // the previous chunk's fragment reads are done
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bv[b] = sB[wj + 16 * b + r][4 * ks + g];
+      for (int h = 0; h < 2; ++h) {
+        uint32_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float a0 = va[h][2 * c], a1 = va[h][2 * c + 1], b0 = vb[h][2 * c], b1 = vb[h][2 * c + 1];
+          ah[c] = pack2_bf16(a0, a1);
+          bh[c] = pack2_bf16(b0, b1);
+          al[c] = pack2_bf16(a0 - __uint_as_float(ah[c] << 16), a1 - __uint_as_float(ah[c] & 0xffff0000u));
+          bl[c] = pack2_bf16(b0 - __uint_as_float(bh[c] << 16), b1 - __uint_as_float(bh[c] & 0xffff0000u));
+        }
+        const int off = (srow + 32 * h) * kPitch + scol;
+        *reinterpret_cast<uint2*>(&sT[0][off]) = make_uint2(ah[0], ah[1]);
+        *reinterpret_cast<uint2*>(&sT[1][off]) = make_uint2(al[0], al[1]);
+        *reinterpret_cast<uint2*>(&sT[2][off]) = make_uint2(bh[0], bh[1]);
+        *reinterpret_cast<uint2*>(&sT[3][off]) = make_uint2(bl[0], bl[1]);
+      }
+      __syncthreads();
+      bf16x8 fa[2][2], fb[2][2];                      // [tile][hi / lo]: row (lane & 15), k = 8 * (lane >> 4) .. + 7
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          fa[t][q] = *reinterpret_cast<const bf16x8*>(&sT[q][(wi + 16 * t + r) * kPitch + 8 * g]);
+          fb[t][q] = *reinterpret_cast<const bf16x8*>(&sT[2 + q][(wj + 16 * t + r) * kPitch + 8 * g]);
+        }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][1], fb[b][0], acc[a][b], 0, 0, 0);      // small terms first
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[b][1], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a][0], fb[b][0], acc[a][b], 0, 0, 0);
+        }
     }
-  }
-  const float inv = 1.0f / ((float)d * (float)d);
-  double sum = 0.0;
+    float tsum = 0.f;                                 // <= 16 terms in (0, 1]: f32 is exact enough before the double accumulator
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int j = j0 + wj + 16 * b + r;
+      for (int b = 0; b < 2; ++b) {
+        const int j = j0 + wj + 16 * b + r;
+        const float nbj = j < n ? nB[j] : 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + wi + 16 * a + 4 * g + q;      // D layout: row = 4*(lane>>4) + reg, col = lane&15
-        if (i < n && j < n) {
-          const float d2 = fmaxf(nA[i] + nB[j] - 2.0f * acc[a][b][q], 0.f);
-          sum += (double)expf(-d2 * inv);
+        for (int q = 0; q < 4; ++q) {
+          const int i = i0 + wi + 16 * a + 4 * g + q;      // D layout: row = 4*(lane>>4) + reg, col = lane&15
+          if (i < n && j < n) tsum += exp2f(fmaxf(nA[i] + nbj - 2.0f * acc[a][b][q], 0.f) * nscale);
         }
       }
-    }
-  if (which < 2 && jt > it) sum *= 2.0;
-  block_atomic_add_d(which == 2 ? -2.0 * sum : sum, out);
+    const double w = m.which == 2 ? -2.0 : ((m.jt > m.it) ? 2.0 : 1.0);
+    sum += w * (double)tsum;
+  }
+  block_atomic_add_d(sum, out);
 }
 
 int launch_mmd_fwd(const float* x, const float* y, int n, int d, double* out, hipStream_t s) {
@@ -287,7 +348,8 @@ int launch_mmd_fwd_mfma(const float* x, const float* y, int n, int d, float* scr
   const int tiles = (n + 63) / 64;
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, n, d, scratch);
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, s, y, n, d, scratch + n);
-  hipLaunchKernelGGL(mmd_fwd_mfma_kernel, dim3(tiles, tiles, 3), dim3(256), 0, s, x, y, scratch, scratch + n, n, d, out);
+  const int total = 2 * ((tiles + 1) / 2) * (tiles + 1) + tiles * tiles;
+  hipLaunchKernelGGL(mmd_fwd_mfma_kernel, dim3(total < 1024 ? total : 1024), dim3(256), 0, s, x, y, scratch, scratch + n, n, d, tiles, out);
   return check_launch("mmd_fwd_mfma");
 }
 
