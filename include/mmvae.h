@@ -80,6 +80,13 @@ MMVAE_API int mmvae_decoder_fwd(mmvae_net* net, int N, const float* encoding, co
 MMVAE_API int mmvae_decoder_bwd(mmvae_net* net, int N, const float* d_recon, const float* params, float* grads, void* workspace,
                       size_t workspace_bytes, float* d_encoding /* may be NULL */, void* stream);
 
+/* Weight gradients run on a side stream owned by the net.  By default every backward entry point orders
+ * them before `stream` again when it returns.  mmvae_net_defer_join(net, 1): mmvae_decoder_bwd leaves its weight gradients in
+ * flight; they are ordered before `stream` by the next mmvae_encoder_bwd on this net or by mmvae_net_join(net, stream), whichever
+ * comes first -- call one of them before anything on `stream` reads the decoder's gradients (optimizer, all-reduce). */
+MMVAE_API int mmvae_net_defer_join(mmvae_net* net, int enable);
+MMVAE_API int mmvae_net_join(mmvae_net* net, void* stream);
+
 /* ------------------------------------------------------------------ latent + loss (model.py:148-150, :364-406)
  * Reparameterisation  enc = mu + eps * exp(0.5*logvar)  (VAE_Encoder.rsample, model.py:148-150). */
 MMVAE_API int mmvae_rsample_fwd(const float* mu, const float* logvar, const float* eps, float* enc, int64_t n, void* stream);

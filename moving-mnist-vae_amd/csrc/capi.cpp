@@ -82,6 +82,16 @@ int mmvae_decoder_bwd(mmvae_net* n, int N, const float* d_recon, const float* pa
   return n->net->decoder_bwd(N, d_recon, params, grads, ws, wsb, d_enc, S(stream));
 }
 
+int mmvae_net_defer_join(mmvae_net* n, int enable) {
+  if (!n) { set_error("net_defer_join: bad argument"); return MMVAE_ERR_ARG; }
+  n->net->set_defer_join(enable != 0);
+  return MMVAE_OK;
+}
+int mmvae_net_join(mmvae_net* n, void* stream) {
+  if (!n) { set_error("net_join: bad argument"); return MMVAE_ERR_ARG; }
+  return n->net->join(S(stream));
+}
+
 // ---- latent / loss
 int mmvae_rsample_fwd(const float* mu, const float* lv, const float* eps, float* enc, int64_t n, void* st) {
   return launch_rsample_fwd(DT_F32, mu, lv, eps, enc, nullptr, (long)n, S(st));

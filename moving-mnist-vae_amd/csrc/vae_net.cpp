@@ -134,6 +134,10 @@ const Plan& Net::plan(int N) {
   P.partials = take(2 * kPartialFloats * 4);       // second half: the shortcut branch running on the side stream
   for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
   for (int i = 0; i < 2; ++i) { P.dy1[i] = take(maxact); P.dy2[i] = take(maxact); P.dys[i] = take(maxact); }
+  for (int i = 0; i < 2; ++i) {
+    const long nb = (long)N * enc[i + 2].Hout * enc[i + 2].Wout * enc[i + 2].C * e;
+    P.edy1[i] = take(nb); P.edy2[i] = take(nb); P.edys[i] = take(nb);
+  }
   P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
   P.wscratch = take((long)kWgradScratchBytes);
@@ -456,7 +460,11 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     const float* xb = i == 0 ? bnf(bn0, base, 3) : nullptr;
     // dy1 / dy2 / dys alternate between two sets, so this block only has to wait for the weight gradients of the block
     // before the previous one (the side stream may lag one block behind)
+    // Blocks 3 and 2 (small tensors) own private sets: with a deferred decoder join the side stream may still be reading the
+    // shared sets for the decoder's weight gradients when they start.  Block 1 waits for block 3's mark, which -- the side
+    // stream being in order -- also covers everything the decoder left there.
     const int ds = i & 1;
+    const long dy1o = i >= 2 ? P.edy1[i - 2] : P.dy1[ds], dy2o = i >= 2 ? P.edy2[i - 2] : P.dy2[ds], dyso = i >= 2 ? P.edys[i - 2] : P.dys[ds];
     if (i + 2 <= 3) MM_TRY(side_wait_mark(i + 2, s));
     // join backward: g = d_out * [out > 0] feeds bn2 (y2) and the shortcut BN (ys)
     int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npix, B.C, part, s,
@@ -465,28 +473,28 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, cnt, s));
     MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, cnt, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
-                               bnf(B.b2, base, 6), base + P.dy2[ds], base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                               base + P.dys[ds], npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
+                               bnf(B.b2, base, 6), base + dy2o, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
+                               base + dyso, npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c2, N, base + P.dy2[ds], B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
+    MM_TRY(run_wgrad(B.c2, N, base + dy2o, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
                      bnf(B.b1, base, 3), grads, wsm));
-    MM_TRY(run_wgrad(B.cs, N, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
-    MM_TRY(run_up(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
+    MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    MM_TRY(run_up(B.c2, base, N, base + dy2o, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
     // bn1 + relu backward
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, cnt, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),
-                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + P.dy1[ds], nullptr, nullptr, nullptr, nullptr, nullptr, npix,
+                               bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + dy1o, nullptr, nullptr, nullptr, nullptr, nullptr, npix,
                                B.C, s));
     // conv1 (3x3 s2) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c1, N, base + P.dy1[ds], B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    MM_TRY(run_wgrad(B.c1, N, base + dy1o, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(side_mark(i));
-    MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
-    MM_TRY(run_up(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
+    MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
+    MM_TRY(run_up(B.cs, base, N, base + dyso, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     cur ^= 1;
   }
   // ---- stem: bn0 + relu backward, then the 5x5 weight gradient
@@ -741,7 +749,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       MM_TRY(run_down(dstem, base, N, base + P.dy1[ds], 2, 2, base + P.dh, 1, 1, nullptr, nullptr, 0, nullptr, 0, dt(), s));
       MM_TRY(launch_convert(dt(), DT_F32, base + P.dh, d_enc, (long)N * cfg.z, s));
     }
-    MM_TRY(side_join(s));
+    if (!defer_join_) MM_TRY(side_join(s));
   }
   return MMVAE_OK;
 }

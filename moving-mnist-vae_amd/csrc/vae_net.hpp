@@ -34,6 +34,8 @@ struct Plan {
   long packed;                                           // packed weights (T)
   long bnws;                                             // float scratch for all BNs
   long partials;                                         // reduction partials (floats)
+  long edy1[2], edy2[2], edys[2];                         // private dy sets of encoder blocks 2 and 3 (index i - 2): the side
+                                                          // stream may still read the shared sets for the decoder when they run
   long g[2], dy1[2], dy2[2], dys[2], da1, dh;            // backward temporaries (dy*: two sets, alternating per block, so the
                                                          // weight gradients on the side stream may lag one block behind)
   long wscratch;                                         // [tap][a][b] reduction image of the largest weight gradient
@@ -107,6 +109,12 @@ class Net {
   // Last up-block forward as one kernel (join + tail conv, the joined activation is never stored); the backward then needs the
   // recomputing wgrad and the recomputing join backward.  MMVAE_TAIL_FWD_FUSED=0 restores join -> conv.
   bool tail_fwd_fused() const;
+  // decoder_bwd leaves its weight gradients running on the side stream; encoder_bwd (or join()) orders them before the caller's stream
+  bool defer_join_ = false;
+ public:
+  void set_defer_join(bool v) { defer_join_ = v; }
+  int join(hipStream_t s) { return side_join(s); }
+ private:
   int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0);
   int bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s);
   float* bnf(const Bn& bn, char* base, int which) const;   // 0 mean 1 istd 2 scale 3 shift 4 A 5 B 6 C

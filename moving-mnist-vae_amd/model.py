@@ -30,6 +30,8 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_DEFER_JOIN = os.environ.get("MMVAE_DEFER_JOIN", "1") != "0"   # developer A/B switch
+
 class _Scope(nn.Module):
     """Name-space node of the module tree (mirrors the reference's nesting so state_dict keys match)."""
 
@@ -113,8 +115,17 @@ class _DecoderFn(torch.autograd.Function):
         G = model._grad_target()
         G[model._dec_off:].zero_()
         ws = model._workspace(N, True)
+        # Single process: the decoder's weight gradients stay in flight on the net's side stream while the encoder backward is
+        # enqueued; mmvae_encoder_bwd orders them before this stream again, and so does the end-of-backward callback below when
+        # the graph holds no encoder (a decoder driven from a leaf encoding).  With a GradSync attached the decoder bucket is
+        # all-reduced right away, so the join stays inside mmvae_decoder_bwd.
+        defer = model._sync is None and _DEFER_JOIN
+        check(lib().mmvae_net_defer_join(model._h, int(defer)), "mmvae_net_defer_join")
         check(lib().mmvae_decoder_bwd(model._h, N, ptr(d_recon), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), ptr(d_enc), _stream()),
               "mmvae_decoder_bwd")
+        if defer:
+            h, st = model._h, _stream()
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: check(lib().mmvae_net_join(h, st), "mmvae_net_join"))
         if model._sync is not None:
             model._sync.bucket_ready(G, model._dec_off, model._n_params)
         return (None, d_enc) + model._grad_views(G, 1)

@@ -313,3 +313,40 @@ if __name__ == "__main__":
                 import traceback
                 traceback.print_exc()
                 print(f"[{dt}] {name}: EXCEPTION {ex!r}"[:400], flush=True)
+
+
+def test_deferred_side_join_decoder_only_backward():
+    """A backward pass that stops at the decoder (leaf encoding, no mmvae_encoder_bwd to order the side stream): the
+    end-of-backward callback must still put the decoder's weight gradients in front of the caller's stream.  Compared with the
+    same pass with the join inside mmvae_decoder_bwd (mmvae_net_defer_join(net, 0)): equal up to the summation order of the float
+    atomics some reductions end with (1e-5 of each tensor's scale; a missing join leaves whole tensors at zero or half summed)."""
+    M = _M()
+    L = importlib.import_module("moving-mnist-vae_amd._lib")
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    m = M.VAE(1, 32, 1, 2, 32, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype="bf16").to(dev).train()
+    N = 256
+    enc = torch.randn(N, 32, 1, 1, device=dev, requires_grad=True)
+    w = torch.randn(N, 1, 64, 64, device=dev)
+
+    def grads(defer):
+        old = M._DEFER_JOIN
+        M._DEFER_JOIN = defer
+        try:
+            m.zero_grad()
+            enc.grad = None
+            (m._decode(enc) * w).sum().backward()
+            out = [p.grad.detach().clone() for p in m._dec_params] + [enc.grad.detach().clone()]
+        finally:
+            M._DEFER_JOIN = old
+        return out
+
+    ref = grads(False)
+    for _ in range(3):
+        got = grads(True)
+        names = [n for n, _ in m.named_parameters() if n.startswith("decoder.")] + ["d_encoding"]
+        bad = {n: (float((a - b).abs().max()), float(b.abs().max())) for n, a, b in zip(names, got, ref)
+               if float((a - b).abs().max()) > 1e-5 * float(b.abs().max()) + 1e-12}
+        bad.pop("decoder.conv2.bias", None)      # analytically zero (a bias in front of BatchNorm): pure cancellation noise
+        assert not bad, bad
+    assert any(float(g.abs().max()) > 0 for g in ref)
