@@ -319,7 +319,9 @@ int launch_bn_bwd_reduce(int dt, const void* dout, const void* out, const float*
                       : launch_bn_bwd_reduce_t<bf16_t>(dout, out, msk_scale, msk_shift, msk_scale1, msk_shift1, y0, y1, npix, C, partials, s);
 }
 
-__global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
+// blockIdx.y selects the BatchNorm: the two branches of a residual join (same partials, which = 0 / 1) finalise in one launch
+__global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a0, BnBwdFinalizeArgs a1) {
+  const BnBwdFinalizeArgs& a = blockIdx.y ? a1 : a0;
   __shared__ double sRed[2 * 4];
   const int c = blockIdx.x;
   const int rows = 1 + a.ny;
@@ -348,8 +350,13 @@ __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a) {
   }
 }
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a.C), dim3(256), 0, s, a, a);
   return check_launch("bn_bwd_finalize");
+}
+int launch_bn_bwd_finalize2(const BnBwdFinalizeArgs& a0, const BnBwdFinalizeArgs& a1, hipStream_t s) {
+  if (a0.C != a1.C) { set_error("bn_bwd_finalize2: channel counts differ"); return MMVAE_ERR_ARG; }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(a0.C, 2), dim3(256), 0, s, a0, a1);
+  return check_launch("bn_bwd_finalize2");
 }
 
 template <typename T, int NY, int MODE>

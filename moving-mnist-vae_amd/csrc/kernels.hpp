@@ -197,6 +197,7 @@ struct BnBwdFinalizeArgs {
   const float* gamma; const float* mean; const float* istd; float* dgamma; float* dbeta; float* coefA; float* coefB; float* coefC;
 };
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
+int launch_bn_bwd_finalize2(const BnBwdFinalizeArgs& a0, const BnBwdFinalizeArgs& a1, hipStream_t s);   // two BNs of equal width, one launch
 // dy0 = A0*g + B0*y0 + C0 ; (dy1 = A1*g + B1*y1 + C1)
 int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
                         const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,

@@ -242,14 +242,27 @@ int Net::bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* ba
                                bnf(bn, base, 2), bnf(bn, base, 3), s);
 }
 
+BnBwdFinalizeArgs Net::bwd_finalize_args(const Bn& bn, const float* params, float* grads, char* base, const float* partials, int nparts, int ny,
+                                         int which, double count) const {
+  const Net& net = *this;
+  BnBwdFinalizeArgs a;
+  a.partials = partials; a.nparts = nparts; a.C = bn.C; a.which = which; a.ny = ny;
+  a.count = count; a.gamma = params + bn.g_off; a.mean = net.bnf(bn, base, 0); a.istd = net.bnf(bn, base, 1);
+  a.dgamma = grads + bn.g_off; a.dbeta = grads + bn.b_off;
+  a.coefA = net.bnf(bn, base, 4); a.coefB = net.bnf(bn, base, 5); a.coefC = net.bnf(bn, base, 6);
+  return a;
+}
 int Net::bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
                            hipStream_t s) {
-  BnBwdFinalizeArgs a;
-  a.partials = reinterpret_cast<const float*>(base + plan_.partials); a.nparts = nparts; a.C = bn.C; a.which = which; a.ny = ny;
-  a.count = count; a.gamma = params + bn.g_off; a.mean = bnf(bn, base, 0); a.istd = bnf(bn, base, 1);
-  a.dgamma = grads + bn.g_off; a.dbeta = grads + bn.b_off;
-  a.coefA = bnf(bn, base, 4); a.coefB = bnf(bn, base, 5); a.coefC = bnf(bn, base, 6);
-  return launch_bn_bwd_finalize(a, s);
+  return launch_bn_bwd_finalize(bwd_finalize_args(bn, params, grads, base, reinterpret_cast<const float*>(base + plan_.partials), nparts, ny,
+                                                  which, count), s);
+}
+// the two BatchNorms of a residual join (partials rows: sum g, sum g*y2, sum g*ys) in one launch
+int Net::bn_backward_coefs_join(const Bn& b2, const Bn& bs, const float* params, float* grads, char* base, int nparts, double count,
+                                hipStream_t s) {
+  const float* part = reinterpret_cast<const float*>(base + plan_.partials);
+  return launch_bn_bwd_finalize2(bwd_finalize_args(b2, params, grads, base, part, nparts, 2, 0, count),
+                                 bwd_finalize_args(bs, params, grads, base, part, nparts, 2, 1, count), s);
 }
 
 // ------------------------------------------------------------------------------------------------ weight re-packs per entry point
@@ -470,8 +483,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npix, B.C, part, s,
                                   bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);
-    MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, cnt, s));
-    MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, cnt, s));
+    MM_TRY(bn_backward_coefs_join(B.b2, B.bs, params, grads, base, np, cnt, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
                                bnf(B.b2, base, 6), base + dy2o, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
                                base + dyso, npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
@@ -701,8 +713,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
                                 bnf(B.bs, base, 2), bnf(B.bs, base, 3));
     MM_TRY(np);
-    MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
-    MM_TRY(bn_backward_coefs(B.bs, params, grads, base, np, 2, 1, (double)npo, s));
+    MM_TRY(bn_backward_coefs_join(B.b2, B.bs, params, grads, base, np, (double)npo, s));
     if (from_tail)
       MM_TRY(launch_tail_join_bwd_apply(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
                                         bnf(B.bs, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5), bnf(B.b2, base, 6), base + P.dy2[ds],

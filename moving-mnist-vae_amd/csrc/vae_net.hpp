@@ -120,6 +120,9 @@ class Net {
   float* bnf(const Bn& bn, char* base, int which) const;   // 0 mean 1 istd 2 scale 3 shift 4 A 5 B 6 C
   int bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
                         hipStream_t s);
+  BnBwdFinalizeArgs bwd_finalize_args(const Bn& bn, const float* params, float* grads, char* base, const float* partials, int nparts, int ny,
+                                      int which, double count) const;
+  int bn_backward_coefs_join(const Bn& b2, const Bn& bs, const float* params, float* grads, char* base, int nparts, double count, hipStream_t s);
 };
 
 }  // namespace mmvae
