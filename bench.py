@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over the global batch (default: per rank)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,7 +146,7 @@ def main():
     model = M.VAE(1, 32, 1, 2, a.z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype=a.dtype).to(device).train()
     opt = M.FusedAdam(list(model.parameters()))
     if world > 1:
-        M.GradSync(model)
+        M.GradSync(model, sync_bn=a.sync_bn)
     args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
     batch = synthetic_clips(a.clips, 1234 + rank, device)
     frames = a.clips * 20
@@ -179,7 +180,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {a.clips} clips x 20 frames x 64x64 per GPU per step (={frames} frames), "
                                    f"conv-VAE z={a.z}, Gaussian NLL sigma=0.1 + KL (normal_vae_1_kl_0_mmd), Adam, "
                                    f"random-init weights, Bernoulli({P_ON}) q=2 labels",
-                       "global_frames_per_step": world * frames, "parallelism": f"dp{world}", "bn": "per-rank batch statistics"},
+                       "global_frames_per_step": world * frames, "parallelism": f"dp{world}", "bn": "global batch statistics (SyncBN)" if (a.sync_bn and world > 1) else "per-rank batch statistics"},
             "frames_per_sec_per_gpu": value / world,
             "final_loss": losses[-1],
             "step_hbm_roofline": {"algorithmic_bytes_per_frame": TRAIN_BYTES_PER_FRAME, "achieved_GBs": value / world * TRAIN_BYTES_PER_FRAME / 1e9,

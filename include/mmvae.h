@@ -87,6 +87,14 @@ MMVAE_API int mmvae_decoder_bwd(mmvae_net* net, int N, const float* d_recon, con
 MMVAE_API int mmvae_net_defer_join(mmvae_net* net, int enable);
 MMVAE_API int mmvae_net_join(mmvae_net* net, void* stream);
 
+/* SyncBN: BatchNorm statistics over the global batch of a data-parallel job.  `fn` must SUM the `n` f32 values at
+ * device pointer `buf` over all ranks in place, ordered on `stream` (the caller's stream or the net's side stream), and return 0;
+ * it is called from inside the four network entry points, in the same order on every rank (two per BatchNorm and direction).
+ * `world` = number of ranks; equal shards per rank are assumed (count = local count * world).  dgamma / dbeta stay per-rank
+ * sums, like every other parameter gradient.  fn == NULL restores per-rank statistics. */
+typedef int (*mmvae_allreduce_fn)(float* buf, int64_t n, void* stream, void* user);
+MMVAE_API int mmvae_net_set_sync_bn(mmvae_net* net, mmvae_allreduce_fn fn, void* user, int world);
+
 /* ------------------------------------------------------------------ latent + loss (model.py:148-150, :364-406)
  * Reparameterisation  enc = mu + eps * exp(0.5*logvar)  (VAE_Encoder.rsample, model.py:148-150). */
 MMVAE_API int mmvae_rsample_fwd(const float* mu, const float* logvar, const float* eps, float* enc, int64_t n, void* stream);

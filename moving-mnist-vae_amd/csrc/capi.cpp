@@ -92,6 +92,12 @@ int mmvae_net_join(mmvae_net* n, void* stream) {
   return n->net->join(S(stream));
 }
 
+int mmvae_net_set_sync_bn(mmvae_net* n, mmvae_allreduce_fn fn, void* user, int world) {
+  if (!n || (fn && world < 1)) { set_error("net_set_sync_bn: bad argument"); return MMVAE_ERR_ARG; }
+  n->net->set_sync_bn(reinterpret_cast<mmvae::Net::AllReduceFn>(fn), user, world);
+  return MMVAE_OK;
+}
+
 // ---- latent / loss
 int mmvae_rsample_fwd(const float* mu, const float* lv, const float* eps, float* enc, int64_t n, void* st) {
   return launch_rsample_fwd(DT_F32, mu, lv, eps, enc, nullptr, (long)n, S(st));

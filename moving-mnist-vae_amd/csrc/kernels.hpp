@@ -177,6 +177,7 @@ struct BnFinalizeArgs {
   float* mean; float* istd; float* scale; float* shift; float momentum, eps;
 };
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+int launch_partial_rowsum(const float* partials, int nparts, int width, float* out, hipStream_t s);   // SyncBN: [nparts][width] -> [width]
 // eval: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
 int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                           float* scale, float* shift, hipStream_t s);

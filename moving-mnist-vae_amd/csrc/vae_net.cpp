@@ -132,6 +132,7 @@ const Plan& Net::plan(int N) {
   P.packed = take(n_packed * e);
   P.bnws = take(n_bnws * 4);
   P.partials = take(2 * kPartialFloats * 4);       // second half: the shortcut branch running on the side stream
+  P.syncbuf = take(2 * 1024 * 4);
   for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
   for (int i = 0; i < 2; ++i) { P.dy1[i] = take(maxact); P.dy2[i] = take(maxact); P.dys[i] = take(maxact); }
   for (int i = 0; i < 2; ++i) {
@@ -225,10 +226,26 @@ bool Net::tail_fwd_fused() const {
          tail_join_fusable(dt(), cfg.out_ch, 1, Sd, Sd);
 }
 
+// SyncBN: sum the partial rows locally, let the host's collective sum the row over the ranks (stream-ordered), and hand the
+// finalize kernels that one row.  Two operand slots: the caller's stream and the side stream may both have one in flight.
+int Net::sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out) {
+  if (width > 1024) { set_error("sync_bn: %d statistics per BatchNorm > 1024", width); return MMVAE_ERR_UNSUPPORTED; }
+  float* buf = reinterpret_cast<float*>(base + plan_.syncbuf) + (s == side_ ? 1024 : 0);
+  MM_TRY(launch_partial_rowsum(partials, nparts, width, buf, s));
+  if (ar_fn_(buf, width, s, ar_user_) != 0) { set_error("sync_bn: the all-reduce callback failed"); return MMVAE_ERR_ARG; }
+  *out = buf;
+  return MMVAE_OK;
+}
+
 int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s,
                   long part_off) {
   BnFinalizeArgs a;
   a.partials = reinterpret_cast<const float*>(base + plan_.partials) + part_off; a.nparts = nparts; a.C = bn.C; a.count = count;
+  if (ar_fn_) {      // statistics over the global batch (equal shards per rank)
+    float* row = nullptr;
+    MM_TRY(sync_rows(base, a.partials, nparts, 2 * bn.C, s, &row));
+    a.partials = row; a.nparts = 1; a.count = count * ar_world_;
+  }
   a.gamma = params + bn.g_off; a.beta = params + bn.b_off;
   a.running_mean = bnbuf ? bnbuf + bn.rm_off : nullptr; a.running_var = bnbuf ? bnbuf + bn.rv_off : nullptr;
   a.nbt = nbt ? nbt + bn.nbt_idx : nullptr;
@@ -252,17 +269,33 @@ BnBwdFinalizeArgs Net::bwd_finalize_args(const Bn& bn, const float* params, floa
   a.coefA = net.bnf(bn, base, 4); a.coefB = net.bnf(bn, base, 5); a.coefC = net.bnf(bn, base, 6);
   return a;
 }
+// SyncBN backward: dgamma / dbeta stay the rank's own sums (the gradient all-reduce adds the ranks up), the coefficients of
+// dx = A*g + B*y + C use the sums over the global batch -- so the local finalize runs first and a second one, fed with the
+// all-reduced row, overwrites the coefficients.
 int Net::bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
                            hipStream_t s) {
-  return launch_bn_bwd_finalize(bwd_finalize_args(bn, params, grads, base, reinterpret_cast<const float*>(base + plan_.partials), nparts, ny,
-                                                  which, count), s);
+  const float* part = reinterpret_cast<const float*>(base + plan_.partials);
+  MM_TRY(launch_bn_bwd_finalize(bwd_finalize_args(bn, params, grads, base, part, nparts, ny, which, count), s));
+  if (!ar_fn_) return MMVAE_OK;
+  float* row = nullptr;
+  MM_TRY(sync_rows(base, part, nparts, (1 + ny) * bn.C, s, &row));
+  BnBwdFinalizeArgs g = bwd_finalize_args(bn, params, grads, base, row, 1, ny, which, count * ar_world_);
+  g.dgamma = nullptr; g.dbeta = nullptr;
+  return launch_bn_bwd_finalize(g, s);
 }
 // the two BatchNorms of a residual join (partials rows: sum g, sum g*y2, sum g*ys) in one launch
 int Net::bn_backward_coefs_join(const Bn& b2, const Bn& bs, const float* params, float* grads, char* base, int nparts, double count,
                                 hipStream_t s) {
   const float* part = reinterpret_cast<const float*>(base + plan_.partials);
-  return launch_bn_bwd_finalize2(bwd_finalize_args(b2, params, grads, base, part, nparts, 2, 0, count),
-                                 bwd_finalize_args(bs, params, grads, base, part, nparts, 2, 1, count), s);
+  MM_TRY(launch_bn_bwd_finalize2(bwd_finalize_args(b2, params, grads, base, part, nparts, 2, 0, count),
+                                 bwd_finalize_args(bs, params, grads, base, part, nparts, 2, 1, count), s));
+  if (!ar_fn_) return MMVAE_OK;
+  float* row = nullptr;
+  MM_TRY(sync_rows(base, part, nparts, 3 * b2.C, s, &row));
+  BnBwdFinalizeArgs g2 = bwd_finalize_args(b2, params, grads, base, row, 1, 2, 0, count * ar_world_);
+  BnBwdFinalizeArgs gs = bwd_finalize_args(bs, params, grads, base, row, 1, 2, 1, count * ar_world_);
+  g2.dgamma = g2.dbeta = gs.dgamma = gs.dbeta = nullptr;
+  return launch_bn_bwd_finalize2(g2, gs, s);
 }
 
 // ------------------------------------------------------------------------------------------------ weight re-packs per entry point

@@ -34,6 +34,7 @@ struct Plan {
   long packed;                                           // packed weights (T)
   long bnws;                                             // float scratch for all BNs
   long partials;                                         // reduction partials (floats)
+  long syncbuf;                                          // SyncBN all-reduce operands: 2 x 1024 floats (main / side stream)
   long edy1[2], edy2[2], edys[2];                         // private dy sets of encoder blocks 2 and 3 (index i - 2): the side
                                                           // stream may still read the shared sets for the decoder when they run
   long g[2], dy1[2], dy2[2], dys[2], da1, dh;            // backward temporaries (dy*: two sets, alternating per block, so the
@@ -111,8 +112,13 @@ class Net {
   bool tail_fwd_fused() const;
   // decoder_bwd leaves its weight gradients running on the side stream; encoder_bwd (or join()) orders them before the caller's stream
   bool defer_join_ = false;
+  int (*ar_fn_)(float*, long long, void*, void*) = nullptr; void* ar_user_ = nullptr; int ar_world_ = 1;
+  int sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out);
  public:
   void set_defer_join(bool v) { defer_join_ = v; }
+  // SyncBN: fn sums a device f32 buffer over all ranks, ordered on the given stream; NULL = per-rank statistics
+  typedef int (*AllReduceFn)(float* buf, long long n, void* stream, void* user);
+  void set_sync_bn(AllReduceFn fn, void* user, int world) { ar_fn_ = fn; ar_user_ = user; ar_world_ = fn ? world : 1; }
   int join(hipStream_t s) { return side_join(s); }
  private:
   int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0);

@@ -439,6 +439,14 @@ class VAE(nn.Module):
             self._ws[training] = ws
         return ws
 
+    def _ws_view(self, dev_ptr, n):
+        """f32 view of n floats at a device address inside one of this model's workspaces (SyncBN all-reduce operands)."""
+        for ws in (self._ws.values() if isinstance(self._ws, dict) else self._ws):
+            if ws is not None and ws.data_ptr() <= dev_ptr < ws.data_ptr() + ws.numel():
+                off = dev_ptr - ws.data_ptr()
+                return ws[off:off + 4 * n].view(torch.float32)
+        raise MmvaeError("sync_bn: operand outside the model's workspace")
+
     def _stamp(self, which, training):
         tok = self._stamps.get((which, training), 0) + 1
         self._stamps[(which, training)] = tok
@@ -680,9 +688,12 @@ class GradSync:
     """Data-parallel gradient exchange: one process per GPU, sum-all-reduce (RCCL over xGMI via
     torch.distributed's "nccl" backend) of the flat gradient in two buckets -- decoder gradients are complete
     first and are reduced while the encoder backward still runs -- and 1/world scaling folded into Adam.
-    BatchNorm statistics stay per-rank (like DistributedDataParallel's default)."""
+    BatchNorm statistics stay per-rank (like DistributedDataParallel's default) unless sync_bn=True: then every train-mode
+    BatchNorm normalises with the statistics of the GLOBAL batch (the reference's semantics at the global batch size):
+    the library sums its per-channel partial sums over the ranks through a callback into torch.distributed -- one small
+    all-reduce per BatchNorm and direction, stream-ordered, equal shards per rank assumed."""
 
-    def __init__(self, model, group=None, broadcast=True):
+    def __init__(self, model, group=None, broadcast=True, sync_bn=False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -690,6 +701,24 @@ class GradSync:
         self.handles = []
         self.reduced = []
         model._sync = self
+        self._cb = None
+        if sync_bn:
+            model._ensure_flat()
+
+            def _allreduce(buf, n, stream, user):
+                try:
+                    t = model._ws_view(buf, n)
+                    st = torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream(t.device)
+                    with torch.cuda.stream(st):
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    return 0
+                except Exception:  # noqa: BLE001 -- must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+
+            self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p)(_allreduce)
+            check(lib().mmvae_net_set_sync_bn(model._h, ctypes.cast(self._cb, ctypes.c_void_p), None, self.world), "mmvae_net_set_sync_bn")
         if broadcast and self.world > 1:
             model._ensure_flat() if model._flat.is_cuda else None
             dist.broadcast(model._flat, 0, group=group)

@@ -144,3 +144,86 @@ def test_two_hip_ranks_average_gradients():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _syncbn_worker(rank, world, port, q):
+    """Two ranks, 4 frames each, BatchNorm statistics over the global batch (GradSync(sync_bn=True)) against ONE process
+    running the 8 frames: same loss, same averaged gradients (f32 kernels; rel 2e-4 of each tensor's max, the summation order
+    of the statistics differs), same BatchNorm running statistics."""
+    try:
+        _init(rank, world, port)
+        from oracle import vae_oracle as O
+        pkg = importlib.import_module("moving-mnist-vae_amd")
+        M = importlib.import_module("moving-mnist-vae_amd.model")
+        dev = torch.device("cuda:0")
+        z, S, N = 32, 64, 8
+        n_loc = N // world
+        spec = O.state_spec(1, z, 1, S, True)
+        state = O.filled_state(spec, seed=0)
+        args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
+        labels = O.synthetic_labels(N, S, seed=321).view(N, S * S)
+        g = torch.Generator().manual_seed(77)
+        eps, ts = torch.randn(N, z, 1, 1, generator=g), torch.randn(N, z, generator=g)
+
+        def run(m, lab, e, t):
+            m.injected_eps, m.injected_true_samples = e.to(dev), t.to(dev)
+            img, tgt = pkg.main.prepare_batch(m, lab, dev, args, O.DATA_MEAN, O.DATA_STD)
+            out = m(img)
+            loss = m.loss(tgt, *out, dev, args)[0]
+            m.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).detach().clone()
+
+        m = M.VAE(1, 32, 1, 2, z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, S, compute_dtype="f32")
+        m.load_state_dict(state)
+        m.to(dev).train()
+        sync = M.GradSync(m, sync_bn=True)
+        sl = slice(rank * n_loc, (rank + 1) * n_loc)
+        loss_r, grad_r = run(m, labels[sl], eps[sl], ts[sl])
+        G = m._grad_target()
+        scale = sync.finish(G)                       # sums the buckets over the ranks; Adam would apply `scale`
+        torch.cuda.synchronize()
+        gavg = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).detach().cpu() * scale
+        lsum = torch.tensor([loss_r])
+        dist.all_reduce(lsum)
+        bn = m._bnf.detach().cpu().clone()
+        if rank == 0:
+            ref = M.VAE(1, 32, 1, 2, z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, S, compute_dtype="f32")
+            ref.load_state_dict(state)
+            ref.to(dev).train()
+            loss_1, grad_1 = run(ref, labels, eps, ts)
+            # MMD is a cross-sample term evaluated per rank (SURVEY 8e); its coefficient is 0 here, so the losses agree
+            assert abs(lsum.item() / world - loss_1) <= 2e-5 * abs(loss_1), (lsum.item() / world, loss_1)
+            names = [n for n, _ in ref.named_parameters()]
+            off, bad = 0, {}
+            for n_, p in zip(names, ref.parameters()):
+                a, b = gavg[off:off + p.numel()], grad_1[off:off + p.numel()].cpu()
+                off += p.numel()
+                if n_ == "decoder.conv2.bias":
+                    continue
+                err = float((a - b).abs().max())
+                if err > 2e-4 * float(b.abs().max()) + 1e-9:
+                    bad[n_] = (err, float(b.abs().max()))
+            assert not bad, bad
+            assert float((bn - ref._bnf.detach().cpu()).abs().max()) < 1e-4
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()[-2500:]))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sync_bn_two_ranks_match_one_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, 29541, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
