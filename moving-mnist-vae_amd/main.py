@@ -186,3 +186,53 @@ def quantise_frames(frames_u8, centres, data_mean, data_std):
     check(lib().mmvae_quantise_normalise(ptr(f), f.numel(), ptr(c), c.numel(), float(data_mean), float(data_std), ptr(labels),
                                          ptr(image), torch.cuda.current_stream().cuda_stream), "mmvae_quantise_normalise")
     return labels, image
+
+
+def clips_from_npz_array(arr) -> torch.Tensor:
+    """File layout of movingmnist{train,test}.npz ['arr_0'] is (N, C, W, H) uint8.  The reference dataset transposes it to
+    (N, H, W, C) (movingmnistdataset.py:15) and ToTensor turns every sample into (C, H, W) (main.py:29-31): net effect, the
+    last two axes swap.  Returns the (N, C, H, W) uint8 tensor of clips the rest of the input pipeline works on (host memory)."""
+    a = np.asarray(arr)
+    if a.ndim != 4 or a.dtype != np.uint8:
+        raise ValueError("expected a uint8 array of shape (N, C, W, H)")
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(0, 1, 3, 2)))
+
+
+class MovingMNISTClips:
+    """Device-side replacement for ``DataLoader(MovingMNISTDataset(...), transform=ToTensor + kmeans.predict)``
+    (movingmnistdataset.py:8-27, main.py:21-38, :491-500): the whole uint8 dataset sits in HBM (10 000 clips x 20 x 64 x 64 =
+    819 MB), a batch is an index gather + ONE quantise kernel, and the iterator yields what the reference's loader yields --
+    int64 k-means labels of shape (B, C*H*W) -- so ``train()`` consumes it unchanged.  No host work per step.
+
+    source: a folder holding movingmnisttrain.npz / movingmnisttest.npz, or an (N, C, W, H) uint8 array in the file's layout.
+    centres: the q k-means centres on the ToTensor scale [0, 1] (kmeans_dict['kmeans'].cluster_centers_.ravel())."""
+
+    def __init__(self, source, centres, batch_size, device, train=True, shuffle=True, seed=None, drop_last=False):
+        import os
+        if isinstance(source, (str, os.PathLike)):
+            path = os.path.join(source, "movingmnisttrain.npz" if train else "movingmnisttest.npz")
+            if not os.path.isfile(path):
+                raise FileNotFoundError(path)
+            source = np.load(path)["arr_0"]
+        self.device = torch.device(device)
+        self.clips = clips_from_npz_array(source).to(self.device)
+        self.train_data = self.clips                  # len(dataset.train_data) is read by main.py:506
+        self.centres = torch.as_tensor(centres, dtype=torch.float32).reshape(-1)
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), bool(drop_last)
+        self._gen = torch.Generator(device="cpu")
+        if seed is not None:
+            self._gen.manual_seed(int(seed))
+
+    def __len__(self):
+        n = self.clips.shape[0]
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = self.clips.shape[0]
+        order = torch.randperm(n, generator=self._gen) if self.shuffle else torch.arange(n)
+        order = order.to(self.device)
+        for i in range(len(self)):
+            idx = order[i * self.batch_size:(i + 1) * self.batch_size]
+            frames = self.clips.index_select(0, idx)
+            labels, _ = quantise_frames(frames, self.centres, 0.0, 1.0)
+            yield labels.view(labels.shape[0], -1)

@@ -65,6 +65,39 @@ def test_quantise_frames_matches_kmeans_predict(pkg):
         np.testing.assert_allclose(image.cpu().numpy(), (ref.astype(np.float32) - 0.0521) / 0.2222, rtol=1e-6)
 
 
+def test_clips_from_npz_array_layout(pkg):
+    """The reference reads (N, C, W, H), transposes to (N, H, W, C) (movingmnistdataset.py:15) and ToTensor makes each sample
+    (C, H, W): restated with numpy here, step by step, and compared with the one-transpose form the loader uses."""
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, size=(3, 20, 8, 6), dtype=np.uint8)              # (N, C, W, H), non-square on purpose
+    dataset_view = arr.transpose(0, 3, 2, 1)                                    # dataset: (N, H, W, C)
+    to_tensor = np.stack([s.transpose(2, 0, 1) for s in dataset_view])          # ToTensor on an HWC ndarray: (C, H, W)
+    got = pkg.clips_from_npz_array(arr)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (3, 20, 6, 8)
+    assert np.array_equal(got.numpy(), to_tensor)
+    with pytest.raises(ValueError):
+        pkg.clips_from_npz_array(arr.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_moving_mnist_clips_loader(pkg, tmp_path):
+    """npz on disk -> device-resident clips -> batches of k-means labels shaped like the reference loader's (B, C*H*W)."""
+    rng = np.random.default_rng(1)
+    arr = rng.integers(0, 256, size=(10, 20, 64, 64), dtype=np.uint8)
+    np.savez(tmp_path / "movingmnisttrain.npz", arr)
+    centres = [0.0038, 0.8808]
+    loader = pkg.MovingMNISTClips(str(tmp_path), centres, batch_size=4, device="cuda", shuffle=False)
+    assert len(loader) == 3 and len(loader.train_data) == 10
+    batches = list(loader)
+    assert [tuple(b.shape) for b in batches] == [(4, 81920), (4, 81920), (2, 81920)] and batches[0].dtype == torch.int64
+    x = arr.transpose(0, 1, 3, 2).astype(np.float32) / 255.0                     # ToTensor scale, (N, C, H, W)
+    ref = np.argmin((x[..., None] - np.asarray(centres, dtype=np.float32)) ** 2, axis=-1).reshape(10, -1)
+    assert np.array_equal(torch.cat(batches).cpu().numpy(), ref)
+    shuffled = pkg.MovingMNISTClips(arr, centres, batch_size=10, device="cuda", shuffle=True, seed=3)
+    (b,) = list(shuffled)
+    assert sorted(map(tuple, b.cpu().numpy()[:, :64].tolist())) == sorted(map(tuple, ref[:, :64].tolist()))
+
+
 @pytest.mark.gpu
 def test_fused_adam_resume(pkg, oracle, tmp_path):
     """Save after 2 steps, resume into a fresh model/optimiser, third step equals an uninterrupted run."""
