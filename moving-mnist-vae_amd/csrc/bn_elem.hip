@@ -583,8 +583,8 @@ __global__ __launch_bounds__(256, (OC1 && !WG) ? 3 : 2) void tail_join_bwd_kerne
   float dpre[2] = {0.f, 0.f};
   auto fetch = [&](int t) {
     const long v = (long)t * 256 + tid;
-    q0 = reinterpret_cast<const Vec16*>(y0)[v];
-    q1 = reinterpret_cast<const Vec16*>(y1)[v];
+    q0 = load_nt(reinterpret_cast<const Vec16*>(y0) + v);
+    q1 = load_nt(reinterpret_cast<const Vec16*>(y1) + v);
     if (OC1) {
       const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;      // uniform
       const float* dp = tg.d_raw + (long)n * hw;
@@ -667,8 +667,8 @@ __global__ __launch_bounds__(256, (OC1 && !WG) ? 3 : 2) void tail_join_bwd_kerne
         r0[j] = a0[j] * gg + b0[j] * f0[j] + c0[j];
         r1[j] = a1[j] * gg + b1[j] * f1[j] + c1[j];
       }
-      reinterpret_cast<Vec16*>(dy0)[v] = Elem<T>::pack(r0);
-      reinterpret_cast<Vec16*>(dy1)[v] = Elem<T>::pack(r1);
+      store_nt(reinterpret_cast<Vec16*>(dy0) + v, Elem<T>::pack(r0));
+      store_nt(reinterpret_cast<Vec16*>(dy1) + v, Elem<T>::pack(r1));
     } else {
 #pragma unroll
       for (int j = 0; j < VE; ++j) {
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256, 3) void tail_join_fwd_kernel(TailFwd a, const 
       float f0[VE], f1[VE], x[VE];
       Elem<T>::unpack(q0, f0);
       Elem<T>::unpack(q1, f1);
-      if (k + 1 < npass) { q0 = v0[(long)(k + 1) * 256]; q1 = v1[(long)(k + 1) * 256]; }
+      if (k + 1 < npass) { q0 = v0[(long)(k + 1) * 256]; q1 = v1[(long)(k + 1) * 256]; }   // default policy: the tail of y2 / ys is still in the Infinity Cache
 #pragma unroll
       for (int j = 0; j < VE; ++j) x[j] = fmaxf((f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]), 0.f);
 #pragma unroll

@@ -17,6 +17,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // Activations / packed weights are stored either as f32 or bf16 ("T"); all
 // accumulation is f32.  A "kvec" is one 16-byte vector of T (4 f32 or 8 bf16).
 struct alignas(16) Vec16 { uint32_t w[4]; };
+// Once-read / once-written streams (tensors several times the Infinity Cache): non-temporal 16-byte accesses
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+__device__ __forceinline__ Vec16 load_nt(const Vec16* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  Vec16 r; r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  return r;
+}
+__device__ __forceinline__ void store_nt(Vec16* p, const Vec16& q) {
+  u32x4_t v; v.x = q.w[0]; v.y = q.w[1]; v.z = q.w[2]; v.w = q.w[3];
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+}
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __uint_as_float(((uint32_t)b) << 16);
