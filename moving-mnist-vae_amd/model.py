@@ -115,11 +115,12 @@ class _DecoderFn(torch.autograd.Function):
         G = model._grad_target()
         G[model._dec_off:].zero_()
         ws = model._workspace(N, True)
-        # Single process: the decoder's weight gradients stay in flight on the net's side stream while the encoder backward is
-        # enqueued; mmvae_encoder_bwd orders them before this stream again, and so does the end-of-backward callback below when
-        # the graph holds no encoder (a decoder driven from a leaf encoding).  With a GradSync attached the decoder bucket is
-        # all-reduced right away, so the join stays inside mmvae_decoder_bwd.
-        defer = model._sync is None and _DEFER_JOIN
+        # The decoder's weight gradients stay in flight on the net's side stream while the encoder backward is enqueued;
+        # mmvae_encoder_bwd orders them before this stream again, and so does the end-of-backward callback below when the graph
+        # holds no encoder (a decoder driven from a leaf encoding).  With a GradSync attached the decoder bucket is all-reduced
+        # from a communication stream that waits for this stream AND the side stream (GradSync.bucket_ready), so the caller's
+        # stream is not held up there either.
+        defer = _DEFER_JOIN
         check(lib().mmvae_net_defer_join(model._h, int(defer)), "mmvae_net_defer_join")
         check(lib().mmvae_decoder_bwd(model._h, N, ptr(d_recon), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), ptr(d_enc), _stream()),
               "mmvae_decoder_bwd")
@@ -127,7 +128,7 @@ class _DecoderFn(torch.autograd.Function):
             h, st = model._h, _stream()
             torch.autograd.Variable._execution_engine.queue_callback(lambda: check(lib().mmvae_net_join(h, st), "mmvae_net_join"))
         if model._sync is not None:
-            model._sync.bucket_ready(G, model._dec_off, model._n_params)
+            model._sync.bucket_ready(G, model._dec_off, model._n_params, side_of=model if defer else None)
         return (None, d_enc) + model._grad_views(G, 1)
 
 
@@ -700,6 +701,7 @@ class GradSync:
         self.world = dist.get_world_size(group)
         self.handles = []
         self.reduced = []
+        self._comm_stream = None
         model._sync = self
         self._cb = None
         if sync_bn:
@@ -724,10 +726,22 @@ class GradSync:
             dist.broadcast(model._flat, 0, group=group)
             dist.broadcast(model._bnf, 0, group=group)
 
-    def bucket_ready(self, G, lo, hi):
+    def bucket_ready(self, G, lo, hi, side_of=None):
+        """Start the all-reduce of G[lo:hi].  side_of: the model whose library side stream still carries part of this bucket
+        (deferred join): the collective is then issued from a communication stream that waits for the caller's stream and for
+        that side stream, and the caller's stream goes on with the encoder backward."""
         if self.world == 1:
             return
-        self.handles.append(self.dist.all_reduce(G[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if side_of is None:
+            self.handles.append(self.dist.all_reduce(G[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=G.device)
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream(G.device))
+            with torch.cuda.stream(cs):
+                check(lib().mmvae_net_join(side_of._h, cs.cuda_stream), "mmvae_net_join")
+                self.handles.append(self.dist.all_reduce(G[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.reduced.append((lo, hi))
 
     def reduce_step_scalars(self, groups):
