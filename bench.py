@@ -158,7 +158,7 @@ def largest_launch_roofline(M, device, N, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=256, help="clips (of 20 frames) per GPU per step")
     ap.add_argument("--z", type=int, default=128)
