@@ -113,7 +113,11 @@ def dominant_kernel_roofline(M, device, N, reps=20):
     ms = e0.elapsed_time(e1) / reps
     alg = x.numel() * 2 + y.numel() * 2 + w.numel() * 2
     ach = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+    # HBM bytes per launch of this kernel at N = 5120 from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
+    # separate runs, profiles/r01_summary.md): 164.8 MB + 655.5 MB.  Not collected inside this process; other N: null.
+    traffic = 820.3e6 if N == 5120 else None
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_summary.md" if traffic else None,
             "kernel": "patch_conv_kernel<bf16,bf16,1,4,false,4,true> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16->16 k4 s2, 32x32 -> 64x64; all 4 stride-phases from one LDS patch; isolated launches, cold input)",
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
 
@@ -150,7 +154,9 @@ def largest_launch_roofline(M, device, N, reps=10):
     ms = e0.elapsed_time(e1) / reps
     alg = 4 * y2.numel() * 2 + d_raw.numel() * 4
     ach = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+    traffic = (1472e6 + 1310e6) if N == 5120 else None      # PMC passes as above: 1472 MB fetched + 1310 MB written
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_summary.md" if traffic else None,
             "kernel": "tail_join_bwd_kernel<bf16,apply> @ decoder.uplayer5 join backward fused with the decoder.conv2 dgrad (isolated launches)",
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
 
