@@ -2,7 +2,10 @@
 """Benchmark of the hot path: conv-VAE train step (encoder -> reparameterise -> decoder -> ELBO -> backward -> Adam)
 on synthetic 20x64x64 Moving-MNIST clips (BASELINE.json configs[1]: 256 clips = 5120 frames per GPU, z=128, bf16).
 
-  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N>1: one rank per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process is one of the N ranks;
+      started plainly, it launches `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a child BEFORE
+      touching the GPU itself and exits with the child's code (fails loudly when fewer than N GPUs are visible).
 
 A "step" is one pass of this repo's ``train`` loop body (main.py:371-399 restated) over one batch that is already
 resident in HBM: labels -> normalise -> forward -> loss -> zero_grad -> backward -> FusedAdam.step.  The four scalars of
@@ -40,9 +43,19 @@ def synthetic_clips(clips, seed, device):
     return lab.to(device)
 
 
-def cpu_baseline(clips, steps, z):
-    """The oracle (bit-identical restatement of the reference model.py) timed on this host's cores with
-    torch.optim.Adam, on a bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_oracle(batch, z, warm, steps):
+    """`warm` + `steps` train steps of the CPU oracle (bit-identical restatement of the reference model.py, torch CPU ops,
+    torch.optim.Adam) on one resident batch; returns (mean, min) seconds per step."""
     from oracle import vae_oracle as O
     pkg = importlib.import_module(PKG)
     torch.manual_seed(0)
@@ -50,15 +63,50 @@ def cpu_baseline(clips, steps, z):
     m.tiled_mmd = True
     opt = torch.optim.Adam(list(m.parameters()))
     args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
-    batch = synthetic_clips(clips, 1234, "cpu")
-    pkg.train(m, [batch], opt, torch.device("cpu"), args, data_mean=DATA_MEAN, data_std=DATA_STD)   # warm-up
-    t0 = time.perf_counter()
-    pkg.train(m, [batch] * steps, opt, torch.device("cpu"), args, data_mean=DATA_MEAN, data_std=DATA_STD)
-    dt = time.perf_counter() - t0
-    frames = clips * 20 * steps
-    return {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} train steps of {clips} clips x 20 frames (z={z}, fp32, torch CPU ops, tiled MMD), oracle/vae_oracle.py",
-            "ms_per_step": 1e3 * dt / steps}
+    dev = torch.device("cpu")
+    if warm > 0:
+        pkg.train(m, [batch] * warm, opt, dev, args, data_mean=DATA_MEAN, data_std=DATA_STD)
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        pkg.train(m, [batch], opt, dev, args, data_mean=DATA_MEAN, data_std=DATA_STD)
+        ts.append(time.perf_counter() - t0)
+    return sum(ts) / len(ts), min(ts)
+
+
+def cpu_baseline(z):
+    """the oracle timed on this host's cores, fp32, all threads, >= 3 warm-up + >= 20 timed steps of
+    config 1 (32 frames, z=32), plus a bounded sample of the benchmarked shape (config 2: 20-frame clips, z as benchmarked)."""
+    # all the cores this process may use (cpu affinity / container share), never more threads than torch's own default
+    # (physical cores): oversubscribed oneDNN threads spin and the baseline collapses
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, torch.get_num_threads())))
+    print(f"[bench] cpu baseline: {torch.get_num_threads()} threads on {_cpu_model()}", file=sys.stderr, flush=True)
+    g = torch.Generator(device="cpu"); g.manual_seed(1234)
+    c1_batch = (torch.rand((32, 64, 64), generator=g) < P_ON).long()                 # config 1: 32 single frames
+    # config 1 is tiny (32 frames): all cores oversubscribe it, so it is also timed on 16 threads and the faster one is reported
+    all_threads = torch.get_num_threads()
+    c1_mean, c1_min = _time_oracle(c1_batch, 32, 3, 20)
+    c1_threads = all_threads
+    if all_threads > 16:
+        torch.set_num_threads(16)
+        m16, n16 = _time_oracle(c1_batch, 32, 3, 20)
+        torch.set_num_threads(all_threads)
+        if m16 < c1_mean:
+            c1_mean, c1_min, c1_threads = m16, n16, 16
+    print(f"[bench] cpu baseline config 1: {1e3 * c1_mean:.1f} ms/step on {c1_threads} threads", file=sys.stderr, flush=True)
+    clips, steps = 32, 3
+    c2_mean, c2_min = _time_oracle(synthetic_clips(clips, 1234, "cpu"), z, 1, steps)
+    frames = clips * 20
+    return {"value": frames / c2_mean, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": _cpu_model(),
+            "sample": f"{steps} timed train steps (1 warm-up) of {clips} clips x 20 frames = {frames} frames (z={z}, fp32, torch CPU ops, "
+                      f"tiled MMD), oracle/vae_oracle.py: the benchmarked shape at 1/8 of its batch",
+            "ms_per_step": 1e3 * c2_mean, "ms_per_step_min": 1e3 * c2_min,
+            "config1": {"value": 32 / c1_mean, "unit": "frames/s", "cores": c1_threads, "ms_per_step": 1e3 * c1_mean, "ms_per_step_min": 1e3 * c1_min,
+                        "sample": "BASELINE configs[0]: 32 frames x 64x64, z=32, fp32, 3 warm-up + 20 timed steps"}}
 
 
 def elbo_check(M, device, dtype):
@@ -80,6 +128,20 @@ def elbo_check(M, device, dtype):
         hmu, hlv, henc, hrec = m(image.to(device))
         got = m.loss(image.to(device), hmu, hlv, henc, hrec, device, types.SimpleNamespace())[0].item()
     return abs(got - ref) / abs(ref)
+
+
+def pmc_traffic(kernel_key, N):
+    """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes, tools/profile_round.sh) from the
+    committed table profiles/*_pmc_hbm.csv -- only rows measured on THIS build (source hash) and batch count; else None."""
+    import csv
+    import glob
+    L = importlib.import_module(PKG + "._lib")
+    build = L.build_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")), reverse=True):
+        for r in csv.DictReader(open(path)):
+            if r["build"] == build and int(r["frames"]) == N and r["key"] == kernel_key:
+                return float(r["fetch_bytes"]) + float(r["write_bytes"]), f"{os.path.relpath(path, ROOT)} (build {build})"
+    return None, None
 
 
 def dominant_kernel_roofline(M, device, N, reps=20):
@@ -113,11 +175,9 @@ def dominant_kernel_roofline(M, device, N, reps=20):
     ms = e0.elapsed_time(e1) / reps
     alg = x.numel() * 2 + y.numel() * 2 + w.numel() * 2
     ach = alg / (ms * 1e-3) / 1e9
-    # HBM bytes per launch of this kernel at N = 5120 from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
-    # separate runs, profiles/r01_summary.md): 164.8 MB + 655.5 MB.  Not collected inside this process; other N: null.
-    traffic = 820.3e6 if N == 5120 else None
+    traffic, src = pmc_traffic("uplayer5.conv2.fwd", N)
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_summary.md" if traffic else None,
+            "traffic_source": src,
             "kernel": "patch_conv_kernel<bf16,bf16,1,4,false,4,true> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16->16 k4 s2, 32x32 -> 64x64; all 4 stride-phases from one LDS patch; isolated launches, cold input)",
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
 
@@ -154,11 +214,37 @@ def largest_launch_roofline(M, device, N, reps=10):
     ms = e0.elapsed_time(e1) / reps
     alg = 4 * y2.numel() * 2 + d_raw.numel() * 4
     ach = alg / (ms * 1e-3) / 1e9
-    traffic = (1472e6 + 1310e6) if N == 5120 else None      # PMC passes as above: 1472 MB fetched + 1310 MB written
+    traffic, src = pmc_traffic("uplayer5.join_bwd_apply", N)
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/r01_summary.md" if traffic else None,
+            "traffic_source": src,
             "kernel": "tail_join_bwd_kernel<bf16,apply> @ decoder.uplayer5 join backward fused with the decoder.conv2 dgrad (isolated launches)",
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
+
+
+def step_traffic(N):
+    """Whole-step HBM bytes (sum over every launch of one train step, FETCH_SIZE x 2 + WRITE_SIZE) from the committed PMC table
+    of this build, against the ideal-fusion byte count the step roofline uses."""
+    total, src = pmc_traffic("__step__", N)
+    if total is None:
+        return None
+    ideal = TRAIN_BYTES_PER_FRAME * N
+    return {"hbm_bytes_per_step": total, "ideal_fusion_bytes_per_step": ideal, "ratio": total / ideal, "source": src}
+
+
+def spawn_ranks(n, argv):
+    """Started without torch.distributed.run: launch the N ranks as a child job (this process has not touched the GPU and
+    never will) and return the child's exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()              # does not initialise the GPU
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible -- refusing to run fewer ranks than asked for")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def main():
@@ -172,11 +258,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over the global batch (default: per rank)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
+                    help="gradient exchange through torch.distributed's nccl(=RCCL) backend, or through the library's own RCCL "
+                         "communicator (mmvae_comm_*)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -192,13 +285,13 @@ def main():
     model = M.VAE(1, 32, 1, 2, a.z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype=a.dtype).to(device).train()
     opt = M.FusedAdam(list(model.parameters()))
     if world > 1:
-        M.GradSync(model, sync_bn=a.sync_bn)
+        M.GradSync(model, sync_bn=a.sync_bn, comm=a.comm)
     args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
     batch = synthetic_clips(a.clips, 1234 + rank, device)
     frames = a.clips * 20
 
-    def run(k):
-        return pkg.train(model, [batch] * k, opt, device, args, data_mean=DATA_MEAN, data_std=DATA_STD)
+    def run(k, b=None):
+        return pkg.train(model, [batch if b is None else b] * k, opt, device, args, data_mean=DATA_MEAN, data_std=DATA_STD)
 
     def fence():
         torch.cuda.synchronize()
@@ -213,10 +306,14 @@ def main():
     losses = run(a.steps)[0]
     fence()
     dt = time.perf_counter() - t0
+    ranks_seen = world
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+        one = torch.ones(1, device=device)
+        dist.all_reduce(one)                  # the RCCL rank count actually taking part
+        ranks_seen = int(one.item())
     if rank == 0:
         value = world * frames * a.steps / dt
         out = {
@@ -226,20 +323,36 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {a.clips} clips x 20 frames x 64x64 per GPU per step (={frames} frames), "
                                    f"conv-VAE z={a.z}, Gaussian NLL sigma=0.1 + KL (normal_vae_1_kl_0_mmd), Adam, "
                                    f"random-init weights, Bernoulli({P_ON}) q=2 labels",
-                       "global_frames_per_step": world * frames, "parallelism": f"dp{world}", "bn": "global batch statistics (SyncBN)" if (a.sync_bn and world > 1) else "per-rank batch statistics"},
+                       "global_frames_per_step": world * frames, "parallelism": f"dp{world}", "rccl_ranks": ranks_seen,
+                       "grad_exchange": ("none" if world == 1 else ("mmvae_comm_allreduce (library RCCL communicator)" if a.comm == "rccl"
+                                                                   else "torch.distributed nccl (= RCCL)")) ,
+                       "bn": "global batch statistics (SyncBN)" if (a.sync_bn and world > 1) else "per-rank batch statistics"},
             "frames_per_sec_per_gpu": value / world,
             "final_loss": losses[-1],
             "step_hbm_roofline": {"algorithmic_bytes_per_frame": TRAIN_BYTES_PER_FRAME, "achieved_GBs": value / world * TRAIN_BYTES_PER_FRAME / 1e9,
                                   "frac_of_8TBs": value / world * TRAIN_BYTES_PER_FRAME / 1e9 / HBM_PEAK_GBS,
                                   "mfma_frac_of_2.5PF": value / world * TRAIN_FLOP_PER_FRAME / 2.5e15},
+            "build": importlib.import_module(PKG + "._lib").build_hash(),
         }
+        out["step_traffic_ratio"] = step_traffic(frames)
+    if world == 1 and not a.no_roofline:
+        # the other reading of "batch 256" (SURVEY 8): 256 FRAMES per step, same model -- a latency-bound point, for reference
+        b256 = (torch.rand((256, 64, 64), generator=torch.Generator().manual_seed(99)) < P_ON).long().to(device)
+        run(3, b256)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(20, b256)
+        torch.cuda.synchronize()
+        d256 = (time.perf_counter() - t1) / 20
+        out["batch256_frames"] = {"frames_per_sec": 256 / d256, "ms_per_step": 1e3 * d256, "note": "256 frames (not clips) per step"}
+    if rank == 0:
         if not a.no_roofline:
             out["roofline"] = dominant_kernel_roofline(M, device, frames)
             if a.dtype == "bf16":
                 out["roofline_largest_launch"] = largest_launch_roofline(M, device, frames)
             out["elbo_rel_err_vs_cpu_oracle"] = elbo_check(M, device, a.dtype)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(32, 3, a.z)
+            out["cpu_baseline"] = cpu_baseline(a.z)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -95,6 +95,21 @@ MMVAE_API int mmvae_net_join(mmvae_net* net, void* stream);
 typedef int (*mmvae_allreduce_fn)(float* buf, int64_t n, void* stream, void* user);
 MMVAE_API int mmvae_net_set_sync_bn(mmvae_net* net, mmvae_allreduce_fn fn, void* user, int world);
 
+/* ------------------------------------------------------------------ data-parallel exchange (the reference has none,
+ * main.py:433-437).  One RCCL communicator per process / GPU; RCCL is bound at run time (the copy already in the process,
+ * else librccl.so / $MMVAE_RCCL_LIB).  Rank 0 creates the id, the host hands its 128 bytes to every rank (e.g. through the
+ * torch.distributed store), every rank calls mmvae_comm_init (a collective).  mmvae_comm_allreduce: in-place f32 SUM over the
+ * ranks, enqueued on `stream` (xGMI ring / tree chosen by RCCL); the gradient buckets and the SyncBN rows use it. */
+typedef struct mmvae_comm mmvae_comm;
+#define MMVAE_COMM_ID_BYTES 128
+MMVAE_API int mmvae_comm_unique_id(void* id_host /* MMVAE_COMM_ID_BYTES, host */);
+MMVAE_API int mmvae_comm_init(mmvae_comm** out, int world, int rank, const void* id_host);
+MMVAE_API int mmvae_comm_allreduce(mmvae_comm* comm, float* buf, int64_t n, void* stream);
+MMVAE_API int mmvae_comm_destroy(mmvae_comm* comm);
+/* SyncBN through the communicator instead of a host callback: the row all-reduces are enqueued in-stream by the library.
+ * comm == NULL restores per-rank statistics. */
+MMVAE_API int mmvae_net_set_sync_bn_comm(mmvae_net* net, mmvae_comm* comm);
+
 /* ------------------------------------------------------------------ latent + loss (model.py:148-150, :364-406)
  * Reparameterisation  enc = mu + eps * exp(0.5*logvar)  (VAE_Encoder.rsample, model.py:148-150). */
 MMVAE_API int mmvae_rsample_fwd(const float* mu, const float* logvar, const float* eps, float* enc, int64_t n, void* stream);
@@ -121,6 +136,8 @@ MMVAE_API int mmvae_ce_bwd(const float* recon, const int64_t* target, const floa
 MMVAE_API int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, float* scratch, double* acc, void* stream);
 /* d_y += coef * d(mmd)/dy */
 MMVAE_API int mmvae_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, void* stream);
+/* k[i][j] = exp(-mean_d((x_i - y_j)^2) / d), out (n, m) f32   (VAE.compute_kernel, model.py:367-376) */
+MMVAE_API int mmvae_rbf_kernel(const float* x, const float* y, int n, int m, int d, float* out, void* stream);
 /* acc = {px, kl, mmd} (f64) -> out[4] = {(nll*px + kl_coef*kl + mmd_coef*mmd)/n, nll*px/n, kl/n, mmd/n}  (model.py:405-406) */
 MMVAE_API int mmvae_loss_finish(const double* acc, float* out, float nll, float kl_coef, float mmd_coef, float n, void* stream);
 
@@ -149,10 +166,12 @@ MMVAE_API int mmvae_conv2d_fwd(int dtype, int transposed, const void* x, const f
 /* dx [N,H,W,Cin] from dy [N,Ho,Wo,Cout] */
 MMVAE_API int mmvae_conv2d_dgrad(int dtype, int transposed, const void* dy, const float* weight, void* dx, int N, int H, int W, int Cin,
                        int Cout, int k, int stride, int pad, void* scratch, void* stream);
-/* dW (f32, weight layout) += ... ; pro_* as in fwd (applied to x) */
+/* dW (f32, weight layout) += ... ; pro_* as in fwd (applied to x).  scratch: MMVAE_WGRAD_SCRATCH_BYTES of device memory
+ * (per-block partial images, summed by a second kernel: no atomics, bit-reproducible), owned by the caller. */
+#define MMVAE_WGRAD_SCRATCH_BYTES (64u << 20)
 MMVAE_API int mmvae_conv2d_wgrad(int dtype, int transposed, const void* x, const void* dy, float* dweight, int N, int H, int W, int Cin,
                        int Cout, int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu,
-                       void* stream);
+                       void* scratch, void* stream);
 /* ---- last up-block + tail conv, one output plane (decoder.uplayerN -> decoder.conv2, reference model.py:86-88,193) ----
  * y2, ys: the two branch outputs [N,H,W,16] of `dtype` (BatchNorm not yet applied); (s2,b2), (ss,bs): per-channel f32
  * scale/shift of their BatchNorms; the block output is x = relu(y2*s2+b2 + ys*ss+bs).  weight f32 (1,16,3,3), bias f32 (1).

@@ -9,7 +9,7 @@ from .main import (MovingMNISTClips, clips_from_npz_array, load_checkpoint, quan
 
 
 def __getattr__(name):
-    if name in ("VAE", "FusedAdam", "DataParallelTrainer"):
+    if name in ("VAE", "FusedAdam", "GradSync", "Communicator", "MmvaeError"):
         from . import model as _m
         return getattr(_m, name)
     raise AttributeError(name)

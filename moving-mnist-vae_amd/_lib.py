@@ -47,7 +47,13 @@ PROTOTYPES = {
     "mmvae_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
     "mmvae_conv2d_fwd": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "mmvae_conv2d_dgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
-    "mmvae_conv2d_wgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "mmvae_conv2d_wgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "mmvae_rbf_kernel": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "mmvae_comm_unique_id": (c_int, [P]),
+    "mmvae_comm_init": (c_int, [POINTER(c_void_p), c_int, c_int, P]),
+    "mmvae_comm_allreduce": (c_int, [P, P, c_int64, P]),
+    "mmvae_comm_destroy": (c_int, [P]),
+    "mmvae_net_set_sync_bn_comm": (c_int, [P, P]),
     "mmvae_tail_join_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_tail_join_bwd_reduce": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_tail_join_bwd_apply": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
@@ -76,6 +82,20 @@ def lib():
         fn.argtypes = args
     _lib = l
     return l
+
+
+def build_hash() -> str:
+    """Short hash of the kernel sources the library was built from (csrc/ + the public header); keys the committed PMC
+    tables under profiles/ to the build they were measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc", ".cpp", ".hpp")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "mmvae.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
 
 
 def check(rc: int, what: str) -> int:

@@ -10,6 +10,7 @@ namespace mmvae { const char* last_error(); }
 using namespace mmvae;
 
 struct mmvae_net { Net* net; };
+struct mmvae_comm { Comm* c; };
 
 static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 
@@ -98,6 +99,37 @@ int mmvae_net_set_sync_bn(mmvae_net* n, mmvae_allreduce_fn fn, void* user, int w
   return MMVAE_OK;
 }
 
+// ---- data-parallel exchange
+int mmvae_comm_unique_id(void* id) {
+  if (!id) { set_error("comm_unique_id: bad argument"); return MMVAE_ERR_ARG; }
+  return comm_unique_id(id);
+}
+int mmvae_comm_init(mmvae_comm** out, int world, int rank, const void* id) {
+  if (!out || !id || world < 1 || rank < 0 || rank >= world) { set_error("comm_init: bad argument"); return MMVAE_ERR_ARG; }
+  mmvae_comm* h = new (std::nothrow) mmvae_comm;
+  if (!h) return MMVAE_ERR_ARG;
+  h->c = nullptr;
+  const int rc = comm_init(&h->c, world, rank, id);
+  if (rc < 0) { delete h; return rc; }
+  *out = h;
+  return MMVAE_OK;
+}
+int mmvae_comm_allreduce(mmvae_comm* c, float* buf, int64_t n, void* st) {
+  if (!c || (!buf && n > 0)) { set_error("comm_allreduce: bad argument"); return MMVAE_ERR_ARG; }
+  return comm_allreduce_sum(c->c, buf, (long long)n, S(st));
+}
+int mmvae_comm_destroy(mmvae_comm* c) {
+  if (!c) return MMVAE_OK;
+  const int rc = comm_destroy(c->c);
+  delete c;
+  return rc;
+}
+int mmvae_net_set_sync_bn_comm(mmvae_net* n, mmvae_comm* c) {
+  if (!n) { set_error("net_set_sync_bn_comm: bad argument"); return MMVAE_ERR_ARG; }
+  n->net->set_sync_bn_comm(c ? c->c : nullptr);
+  return MMVAE_OK;
+}
+
 // ---- latent / loss
 int mmvae_rsample_fwd(const float* mu, const float* lv, const float* eps, float* enc, int64_t n, void* st) {
   return launch_rsample_fwd(DT_F32, mu, lv, eps, enc, nullptr, (long)n, S(st));
@@ -129,6 +161,10 @@ int mmvae_mmd_fwd(const float* x, const float* y, int n, int d, float* scratch, 
 }
 int mmvae_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, void* st) {
   return launch_mmd_bwd(x, y, n, d, coef, gscale, d_y, S(st));
+}
+int mmvae_rbf_kernel(const float* x, const float* y, int n, int m, int d, float* out, void* st) {
+  if (!x || !y || !out) { set_error("rbf_kernel: bad argument"); return MMVAE_ERR_ARG; }
+  return launch_rbf_matrix(x, y, n, m, d, out, S(st));
 }
 int mmvae_loss_finish(const double* acc, float* out, float nll, float kl_coef, float mmd_coef, float n, void* st) {
   return launch_loss_finish(acc, out, nll, kl_coef, mmd_coef, n, S(st));
@@ -180,23 +216,14 @@ int mmvae_conv2d_dgrad(int dt, int transposed, const void* dy, const float* w, v
   return op_run_down(dt, dt, g, scratch, N, dy, Ho, Wo, dx, H, W, nullptr, nullptr, 0, nullptr, 0, S(st));
 }
 int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int k,
-                       int s, int p, const float* ps, const float* pb, int relu, void* st) {
+                       int s, int p, const float* ps, const float* pb, int relu, void* scratch, void* st) {
   const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
   const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
-  (void)numel_w;
-  // partial-image scratch of the single-op entry point: one lazily allocated buffer per device, kept for the process
-  // lifetime (calls on different streams of one device must not overlap; the Net entry points use their own workspace)
-  static float* scratch[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { set_error("conv2d_wgrad: no current device"); return MMVAE_ERR_HIP; }
-  if (!scratch[dev]) {
-    void* p = nullptr;
-    const hipError_t e = hipMalloc(&p, kWgradScratchBytes);
-    if (e != hipSuccess) { set_error("conv2d_wgrad: hipMalloc scratch: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
-    scratch[dev] = static_cast<float*>(p);
-  }
-  if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st), scratch[dev]);
-  return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), scratch[dev]);
+  if (!scratch) { set_error("conv2d_wgrad: scratch (MMVAE_WGRAD_SCRATCH_BYTES) required"); return MMVAE_ERR_ARG; }
+  static_assert(MMVAE_WGRAD_SCRATCH_BYTES == kWgradScratchBytes, "public scratch size out of sync");
+  float* sc = static_cast<float*>(scratch);
+  if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st), sc);
+  return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), sc);
 }
 int mmvae_tail_join_fwd(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
                         const float* w, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* st) {

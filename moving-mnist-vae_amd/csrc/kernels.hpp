@@ -243,6 +243,8 @@ int launch_ce_bwd(const float* r, const long long* t, const float* w, int N, int
 // MMD (sums): out += sum_ij k(x_i,x_j) + sum_ij k(y_i,y_j) - 2 sum_ij k(x_i,y_j), k = exp(-|a-b|^2/d^2)
 int launch_mmd_fwd(const float* x, const float* y, int n, int d, double* out, hipStream_t s);
 int launch_mmd_fwd_mfma(const float* x, const float* y, int n, int d, float* scratch /*2n floats*/, double* out, hipStream_t s);
+// k[i][j] = exp(-|x_i - y_j|^2 / d^2), (n, m) f32  (VAE.compute_kernel, model.py:367-376)
+int launch_rbf_matrix(const float* x, const float* y, int n, int m, int d, float* out, hipStream_t s);
 // d_y[j] += coef * d(mmd)/d(y_j)
 int launch_mmd_bwd(const float* x, const float* y, int n, int d, float coef, const float* gscale, float* d_y, hipStream_t s);
 

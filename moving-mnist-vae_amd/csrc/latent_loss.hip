@@ -202,6 +202,54 @@ __global__ __launch_bounds__(256) void mmd_fwd_kernel(const float* __restrict__ 
       if (i0 + ti + 16 * a < n && j0 + tj + 16 * b < n) sum += (double)expf(-acc[a][b] * inv);
   block_atomic_add_d(which == 2 ? -2.0 * sum : sum, out);
 }
+// VAE.compute_kernel (model.py:367-376): the (n, m) matrix k[i][j] = exp(-mean_d((x_i - y_j)^2) / d) itself (a helper of the
+// reference surface; the loss never materialises it).  Same 64x64 tile / 4x4 pairs per thread scheme as mmd_fwd_kernel.
+__global__ __launch_bounds__(256) void rbf_matrix_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, int m, int d,
+                                                         float* __restrict__ out) {
+  __shared__ float sA[64][33];
+  __shared__ float sB[64][33];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (int k0 = 0; k0 < d; k0 += 32) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < 64 * 32; v += 256) {
+      const int rr = v >> 5, kk = v & 31;
+      sA[rr][kk] = (i0 + rr < n && k0 + kk < d) ? x[(long)(i0 + rr) * d + k0 + kk] : 0.f;
+      sB[rr][kk] = (j0 + rr < m && k0 + kk < d) ? y[(long)(j0 + rr) * d + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = sA[ti + 16 * a][kk];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = sB[tj + 16 * b][kk];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { const float df = av[a] - bv[b]; acc[a][b] += df * df; }
+    }
+  }
+  const float inv = 1.0f / ((float)d * (float)d);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + ti + 16 * a, j = j0 + tj + 16 * b;
+      if (i < n && j < m) out[(long)i * m + j] = expf(-acc[a][b] * inv);
+    }
+}
+int launch_rbf_matrix(const float* x, const float* y, int n, int m, int d, float* out, hipStream_t s) {
+  if (n <= 0 || m <= 0 || d <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(rbf_matrix_kernel, dim3((m + 63) / 64, (n + 63) / 64), dim3(256), 0, s, x, y, n, m, d, out);
+  return check_launch("rbf_matrix");
+}
 // MFMA version (exact f32, v_mfma_f32_16x16x4_f32): a 64x64 tile of pairs per block, each wave a 32x32 quadrant as 2x2
 // MFMA tiles; S = A B^T accumulated over d in LDS chunks of 32, then k = exp(-(|a|^2 + |b|^2 - 2S)/d^2).
 // The symmetric xx / yy sums visit only tiles with j-tile >= i-tile (off-diagonal tiles count twice).

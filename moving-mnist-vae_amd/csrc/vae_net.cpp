@@ -232,7 +232,8 @@ int Net::sync_rows(char* base, const float* partials, int nparts, int width, hip
   if (width > 1024) { set_error("sync_bn: %d statistics per BatchNorm > 1024", width); return MMVAE_ERR_UNSUPPORTED; }
   float* buf = reinterpret_cast<float*>(base + plan_.syncbuf) + (s == side_ ? 1024 : 0);
   MM_TRY(launch_partial_rowsum(partials, nparts, width, buf, s));
-  if (ar_fn_(buf, width, s, ar_user_) != 0) { set_error("sync_bn: the all-reduce callback failed"); return MMVAE_ERR_ARG; }
+  if (comm_) MM_TRY(comm_allreduce_sum(comm_, buf, width, s));
+  else if (ar_fn_(buf, width, s, ar_user_) != 0) { set_error("sync_bn: the all-reduce callback failed"); return MMVAE_ERR_ARG; }
   *out = buf;
   return MMVAE_OK;
 }
@@ -241,7 +242,7 @@ int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nb
                   long part_off) {
   BnFinalizeArgs a;
   a.partials = reinterpret_cast<const float*>(base + plan_.partials) + part_off; a.nparts = nparts; a.C = bn.C; a.count = count;
-  if (ar_fn_) {      // statistics over the global batch (equal shards per rank)
+  if (sync_bn_on()) {      // statistics over the global batch (equal shards per rank)
     float* row = nullptr;
     MM_TRY(sync_rows(base, a.partials, nparts, 2 * bn.C, s, &row));
     a.partials = row; a.nparts = 1; a.count = count * ar_world_;
@@ -276,7 +277,7 @@ int Net::bn_backward_coefs(const Bn& bn, const float* params, float* grads, char
                            hipStream_t s) {
   const float* part = reinterpret_cast<const float*>(base + plan_.partials);
   MM_TRY(launch_bn_bwd_finalize(bwd_finalize_args(bn, params, grads, base, part, nparts, ny, which, count), s));
-  if (!ar_fn_) return MMVAE_OK;
+  if (!sync_bn_on()) return MMVAE_OK;
   float* row = nullptr;
   MM_TRY(sync_rows(base, part, nparts, (1 + ny) * bn.C, s, &row));
   BnBwdFinalizeArgs g = bwd_finalize_args(bn, params, grads, base, row, 1, ny, which, count * ar_world_);
@@ -289,7 +290,7 @@ int Net::bn_backward_coefs_join(const Bn& b2, const Bn& bs, const float* params,
   const float* part = reinterpret_cast<const float*>(base + plan_.partials);
   MM_TRY(launch_bn_bwd_finalize2(bwd_finalize_args(b2, params, grads, base, part, nparts, 2, 0, count),
                                  bwd_finalize_args(bs, params, grads, base, part, nparts, 2, 1, count), s));
-  if (!ar_fn_) return MMVAE_OK;
+  if (!sync_bn_on()) return MMVAE_OK;
   float* row = nullptr;
   MM_TRY(sync_rows(base, part, nparts, 3 * b2.C, s, &row));
   BnBwdFinalizeArgs g2 = bwd_finalize_args(b2, params, grads, base, row, 1, 2, 0, count * ar_world_);

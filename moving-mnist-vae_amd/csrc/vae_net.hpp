@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "comm.hpp"
 #include "kernels.hpp"
 
 namespace mmvae {
@@ -113,12 +114,16 @@ class Net {
   // decoder_bwd leaves its weight gradients running on the side stream; encoder_bwd (or join()) orders them before the caller's stream
   bool defer_join_ = false;
   int (*ar_fn_)(float*, long long, void*, void*) = nullptr; void* ar_user_ = nullptr; int ar_world_ = 1;
+  Comm* comm_ = nullptr;
   int sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out);
  public:
   void set_defer_join(bool v) { defer_join_ = v; }
   // SyncBN: fn sums a device f32 buffer over all ranks, ordered on the given stream; NULL = per-rank statistics
   typedef int (*AllReduceFn)(float* buf, long long n, void* stream, void* user);
-  void set_sync_bn(AllReduceFn fn, void* user, int world) { ar_fn_ = fn; ar_user_ = user; ar_world_ = fn ? world : 1; }
+  void set_sync_bn(AllReduceFn fn, void* user, int world) { ar_fn_ = fn; ar_user_ = user; ar_world_ = fn ? world : 1; comm_ = nullptr; }
+  // SyncBN through an RCCL communicator of this library: the row all-reduce is enqueued in-stream (no host callback, capturable)
+  void set_sync_bn_comm(Comm* c) { comm_ = c; ar_fn_ = nullptr; ar_user_ = nullptr; ar_world_ = c ? comm_world(c) : 1; }
+  bool sync_bn_on() const { return ar_fn_ != nullptr || comm_ != nullptr; }
   int join(hipStream_t s) { return side_join(s); }
  private:
   int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0);

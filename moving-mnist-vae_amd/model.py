@@ -526,6 +526,15 @@ class VAE(nn.Module):
         check(lib().mmvae_kl_fwd(ptr(mu), ptr(lv), mu.numel(), ptr(acc), _stream()), "mmvae_kl_fwd")
         return acc[0].float()
 
+    def compute_kernel(self, x, y):                            # model.py:367-376
+        """(x_size, y_size) matrix exp(-mean_d((x_i - y_j)^2) / d) -- the helper itself; ``loss`` never materialises it."""
+        x, y = x.contiguous().float(), y.contiguous().float()
+        if x.dim() != 2 or y.dim() != 2 or x.shape[1] != y.shape[1]:
+            raise ValueError("compute_kernel expects (n, d) and (m, d)")
+        out = torch.empty((x.shape[0], y.shape[0]), dtype=torch.float32, device=x.device)
+        check(lib().mmvae_rbf_kernel(ptr(x), ptr(y), x.shape[0], y.shape[0], x.shape[1], ptr(out), _stream()), "mmvae_rbf_kernel")
+        return out
+
     def compute_mmd(self, x, y):                               # model.py:378-383
         acc = torch.zeros(1, dtype=torch.float64, device=x.device)
         x, y = x.contiguous().float(), y.contiguous().float()
@@ -576,14 +585,21 @@ class VAE(nn.Module):
         return image, target
 
     def __repr__(self):
-        s = (f"VAE[MI355X/HIP, {self.compute_dtype}]: encoder {self.input_image_size}x{self.input_image_size}x{self.in_channels}"
-             f" -> z={self.z_dimensions}" + (" (Gaussian reparameterisation)" if self.require_rsample else "") +
-             f" -> decoder {self.input_image_size}x{self.input_image_size}x{self.decoder_out_channels}; ")
+        """The reference's description text (model.py:408-439) for the built configurations (pixelcnn is None)."""
+        size = str(self.input_image_size) + "x" + str(self.input_image_size) + "x"
+        rsample_text = " Where Z is rsampled from a Normal Distribution." if self.require_rsample else ""
+        string = ("We are using an encoder which takes input of " + size + str(self.in_channels) + " and encodes into " +
+                  str(self.z_dimensions) + " dimensional latent space." + rsample_text +
+                  " \nIt is then pushed into a decoder which outputs an image of dimension " + size +
+                  str(self.decoder_out_channels) + ".\n")
         if self.decoder_out_channels == self.in_channels:
-            s += f"p(x|z) = Normal(recon, sigma={self.sigma_decoder})"
+            string += "We assume p(x/z) follows a normal distribution with mean x_recon and sigma " + str(self.sigma_decoder) + ".\n"
         else:
-            s += "p(x|z) categorical"
-        return s + f"; loss = {self.nll}*nll + {self.kl}*kl + {self.mmd}*mmd"
+            string += "We assume p(x/z) follows a categorical distribution. \n"
+        return string
+
+    def extra_repr(self):
+        return f"MI355X/HIP backend, compute_dtype={self.compute_dtype}"
 
     def __del__(self):
         try:
@@ -685,16 +701,64 @@ class FusedAdam(torch.optim.Optimizer):
 
 
 # ------------------------------------------------------------------------------------------ data parallel
+class Communicator:
+    """RCCL communicator behind the C ABI (``mmvae_comm_*``, include/mmvae.h): in-place f32 sum all-reduce enqueued on a HIP
+    stream by the library itself.  ``Communicator.from_torch_distributed()`` builds one next to an initialised
+    torch.distributed job (the 128-byte RCCL id travels through the job's own object broadcast)."""
+
+    def __init__(self, world, rank, unique_id: bytes):
+        self._h = ctypes.c_void_p()
+        self.world, self.rank = int(world), int(rank)
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(lib().mmvae_comm_init(ctypes.byref(self._h), self.world, self.rank, ctypes.cast(buf, ctypes.c_void_p)), "mmvae_comm_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        check(lib().mmvae_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "mmvae_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(world, rank, box[0])
+
+    def all_reduce_(self, t: torch.Tensor, stream=None):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise MmvaeError("Communicator.all_reduce_ expects a contiguous f32 GPU tensor")
+        st = _stream() if stream is None else stream
+        check(lib().mmvae_comm_allreduce(self._h, ptr(t), t.numel(), st), "mmvae_comm_allreduce")
+        return t
+
+    def destroy(self):
+        h, self._h = self._h, None
+        if h:
+            check(lib().mmvae_comm_destroy(h), "mmvae_comm_destroy")
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class GradSync:
-    """Data-parallel gradient exchange: one process per GPU, sum-all-reduce (RCCL over xGMI via
-    torch.distributed's "nccl" backend) of the flat gradient in two buckets -- decoder gradients are complete
-    first and are reduced while the encoder backward still runs -- and 1/world scaling folded into Adam.
+    """Data-parallel gradient exchange: one process per GPU, sum-all-reduce over RCCL/xGMI of the flat gradient in two
+    buckets -- decoder gradients are complete first and are reduced while the encoder backward still runs -- and 1/world
+    scaling folded into Adam.  ``comm="torch"`` (default) issues the buckets through torch.distributed (backend "nccl" = RCCL;
+    "gloo" in the CPU tests); ``comm="rccl"`` (or a ``Communicator``) issues them through this library's own RCCL communicator
+    (``mmvae_comm_allreduce``) from a communication stream, with no Python in the SyncBN path.
     BatchNorm statistics stay per-rank (like DistributedDataParallel's default) unless sync_bn=True: then every train-mode
     BatchNorm normalises with the statistics of the GLOBAL batch (the reference's semantics at the global batch size):
-    the library sums its per-channel partial sums over the ranks through a callback into torch.distributed -- one small
-    all-reduce per BatchNorm and direction, stream-ordered, equal shards per rank assumed."""
+    the library sums its per-channel partial sums over the ranks -- one small all-reduce per BatchNorm and direction,
+    stream-ordered (in-stream RCCL call with a Communicator, host callback into torch.distributed otherwise), equal shards per
+    rank assumed."""
 
-    def __init__(self, model, group=None, broadcast=True, sync_bn=False):
+    def __init__(self, model, group=None, broadcast=True, sync_bn=False, comm=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -702,9 +766,18 @@ class GradSync:
         self.handles = []
         self.reduced = []
         self._comm_stream = None
+        self._comm_pending = False
         model._sync = self
         self._cb = None
-        if sync_bn:
+        comm = comm if comm is not None else os.environ.get("MMVAE_COMM", "torch")
+        if isinstance(comm, str):
+            if comm not in ("torch", "rccl"):
+                raise ValueError("comm must be 'torch', 'rccl' or a Communicator")
+            comm = Communicator.from_torch_distributed(group) if comm == "rccl" else None
+        self.comm = comm
+        if sync_bn and self.comm is not None:
+            check(lib().mmvae_net_set_sync_bn_comm(model._h, self.comm._h), "mmvae_net_set_sync_bn_comm")
+        elif sync_bn:
             model._ensure_flat()
 
             def _allreduce(buf, n, stream, user):
@@ -726,22 +799,31 @@ class GradSync:
             dist.broadcast(model._flat, 0, group=group)
             dist.broadcast(model._bnf, 0, group=group)
 
+    def _all_reduce(self, t):
+        """One bucket, on the CURRENT stream context."""
+        if self.comm is not None:
+            self.comm.all_reduce_(t)
+        else:
+            self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def bucket_ready(self, G, lo, hi, side_of=None):
         """Start the all-reduce of G[lo:hi].  side_of: the model whose library side stream still carries part of this bucket
         (deferred join): the collective is then issued from a communication stream that waits for the caller's stream and for
         that side stream, and the caller's stream goes on with the encoder backward."""
         if self.world == 1:
             return
-        if side_of is None:
-            self.handles.append(self.dist.all_reduce(G[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if side_of is None and self.comm is None:
+            self._all_reduce(G[lo:hi])
         else:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=G.device)
             cs = self._comm_stream
             cs.wait_stream(torch.cuda.current_stream(G.device))
             with torch.cuda.stream(cs):
-                check(lib().mmvae_net_join(side_of._h, cs.cuda_stream), "mmvae_net_join")
-                self.handles.append(self.dist.all_reduce(G[lo:hi], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if side_of is not None:
+                    check(lib().mmvae_net_join(side_of._h, cs.cuda_stream), "mmvae_net_join")
+                self._all_reduce(G[lo:hi])
+            self._comm_pending = True
         self.reduced.append((lo, hi))
 
     def reduce_step_scalars(self, groups):
@@ -749,8 +831,11 @@ class GradSync:
         ranks.  `groups` are the _StepScalars of the steps not yet read back."""
         if self.world == 1 or not groups:
             return
-        stacked = torch.stack([g.dev for g in groups])
-        self.dist.all_reduce(stacked, op=self.dist.ReduceOp.SUM, group=self.group)
+        stacked = torch.stack([g.dev for g in groups]).contiguous()
+        if self.comm is not None:
+            self.comm.all_reduce_(stacked)
+        else:
+            self.dist.all_reduce(stacked, op=self.dist.ReduceOp.SUM, group=self.group)
         vals = (stacked / self.world).tolist()
         for g, v in zip(groups, vals):
             g.vals = v
@@ -759,14 +844,23 @@ class GradSync:
         """Wait for the in-flight buckets; returns the factor Adam applies to the summed gradient."""
         for h in self.handles:
             h.wait()
+        if self._comm_pending:                                   # buckets issued from the communication stream
+            torch.cuda.current_stream(G.device).wait_stream(self._comm_stream)
+            self._comm_pending = False
         covered = sorted(self.reduced)
         self.handles, self.reduced = [], []
         if self.world > 1:
             pos = 0
             for lo, hi in covered:
                 if lo > pos:
-                    self.dist.all_reduce(G[pos:lo], op=self.dist.ReduceOp.SUM, group=self.group)
+                    self._all_reduce_now(G[pos:lo])
                 pos = max(pos, hi)
             if pos < G.numel():
-                self.dist.all_reduce(G[pos:], op=self.dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce_now(G[pos:])
         return 1.0 / self.world
+
+    def _all_reduce_now(self, t):
+        if self.comm is not None:
+            self.comm.all_reduce_(t)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)

@@ -1,0 +1,96 @@
+"""GPU: pieces of the drop-in boundary that are not on the train step's critical path -- VAE.compute_kernel
+(model.py:367-376), the RCCL communicator entry points (mmvae_comm_*, world of one on the test box; a real 2-rank RCCL job when
+two GPUs are visible), and the graph-capturability the header promises for the stream-ordered entry points."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _M():
+    return importlib.import_module("moving-mnist-vae_amd.model")
+
+
+def test_compute_kernel_matches_reference_formula(oracle):
+    M = _M()
+    m = M.VAE(1, 32, 1, 2, 32, False, False).to("cuda")
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(70, 32, generator=g), torch.randn(133, 32, generator=g) * 1.5
+    k = m.compute_kernel(x.cuda(), y.cuda()).cpu()
+    ref = oracle.compute_kernel(x, y)                      # restates model.py:367-376 (tiled x / y, mean over dim, / dim, exp)
+    assert k.shape == (70, 133)
+    assert (k - ref).abs().max().item() <= 2e-6
+    mmd = m.compute_mmd(x.cuda(), x.cuda() * 0.5).item()
+    ref64 = oracle.compute_mmd(x.double(), x.double() * 0.5).item()      # the three sums cancel: judge both against f64
+    assert abs(mmd - ref64) <= 2e-5 * 70 * 70
+
+
+def test_rccl_communicator_world_of_one():
+    """mmvae_comm_unique_id / init / allreduce / destroy against the RCCL already loaded by PyTorch-ROCm (dlopen at run time)."""
+    M = _M()
+    c = M.Communicator(1, 0, M.Communicator.unique_id())
+    t = torch.arange(1000, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c.all_reduce_(t)                                   # enqueued on the current (side) stream
+    side.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))
+    c.destroy()
+
+
+def _nccl_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        M = _M()
+        for comm in ("torch", "rccl"):
+            torch.manual_seed(0)
+            m = M.VAE(1, 32, 1, 2, 32, False, False, compute_dtype="bf16").to(f"cuda:{rank}").train()
+            opt = M.FusedAdam(list(m.parameters()))
+            M.GradSync(m, comm=comm)
+            x = torch.randn(8, 1, 64, 64, generator=torch.Generator().manual_seed(rank)).to(f"cuda:{rank}")
+            mu, lv, enc, rec = m(x)
+            loss = m.loss(x, mu, lv, enc, rec, x.device, None)[0]
+            opt.zero_grad(); loss.backward(); opt.step()
+            flat = m._flat.clone()
+            dist.all_reduce(flat)
+            assert torch.allclose(flat / world, m._flat, rtol=0, atol=0), comm      # identical parameters on every rank
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+    finally:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_gradsync_nccl_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, 29547, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import subprocess
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -58,6 +58,16 @@ def _round(t, dt):
     return t.to(torch.bfloat16).float() if dt == "bf16" else t
 
 
+_WSCRATCH = []
+
+
+def _wgrad_scratch():
+    """Caller-owned partial-image scratch of mmvae_conv2d_wgrad (MMVAE_WGRAD_SCRATCH_BYTES), allocated once per process."""
+    if not _WSCRATCH:
+        _WSCRATCH.append(torch.empty(64 << 20, dtype=torch.uint8, device="cuda"))
+    return _WSCRATCH[0]
+
+
 def run_config(cfg, dt, prologue=False):
     """Returns dict of relative errors (max-abs error / max-abs reference) for fwd, dgrad, wgrad, stats."""
     L = _lib()
@@ -98,8 +108,8 @@ def run_config(cfg, dt, prologue=False):
     dxd = torch.full((N, H, H, Cin), float("nan"), device="cuda", dtype=tdt)
     L.check(lib.mmvae_conv2d_dgrad(dti, tr, L.ptr(dyd), L.ptr(wd), L.ptr(dxd), N, H, H, Cin, Cout, k, s, p, L.ptr(scratch), st), "conv2d_dgrad")
     dwd = torch.zeros(wshape, device="cuda")
-    L.check(lib.mmvae_conv2d_wgrad(dti, tr, L.ptr(xd), L.ptr(dyd), L.ptr(dwd), N, H, H, Cin, Cout, k, s, p, L.ptr(psd), L.ptr(pbd), 1, st),
-            "conv2d_wgrad")
+    L.check(lib.mmvae_conv2d_wgrad(dti, tr, L.ptr(xd), L.ptr(dyd), L.ptr(dwd), N, H, H, Cin, Cout, k, s, p, L.ptr(psd), L.ptr(pbd), 1,
+                                   L.ptr(_wgrad_scratch()), st), "conv2d_wgrad")
     torch.cuda.synchronize()
     out = {}
     yh = _from_dev(yd)
