@@ -139,18 +139,18 @@ int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, i
 
 // ---------------------------------------------------------------- SyncBN: partial rows -> one row (the all-reduce operand)
 // partials [nparts][rows][C] -> out [rows * C]: the finalize kernels take the summed row as a single partial row afterwards.
-__global__ __launch_bounds__(256) void partial_rowsum_kernel(const float* __restrict__ partials, int nparts, int width, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void partial_rowsum_kernel(const float* __restrict__ partials, int nparts, int stride, float* __restrict__ out) {
   __shared__ double sRed[4];
   const int col = blockIdx.x;
   double s = 0.0;
-  for (int p = threadIdx.x; p < nparts; p += 256) s += (double)partials[(long)p * width + col];
+  for (int p = threadIdx.x; p < nparts; p += 256) s += (double)partials[(long)p * stride + col];
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) out[col] = (float)((sRed[0] + sRed[1]) + (sRed[2] + sRed[3]));
 }
-int launch_partial_rowsum(const float* partials, int nparts, int width, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(partial_rowsum_kernel, dim3(width), dim3(256), 0, s, partials, nparts, width, out);
+int launch_partial_rowsum(const float* partials, int nparts, int width, float* out, hipStream_t s, int row_stride) {
+  hipLaunchKernelGGL(partial_rowsum_kernel, dim3(width), dim3(256), 0, s, partials, nparts, row_stride > 0 ? row_stride : width, out);
   return check_launch("partial_rowsum");
 }
 

@@ -164,6 +164,14 @@ int launch_tail_dgrad(int dt, const float* dy, const float* w, void* dx, int N, 
 int launch_tail_wgrad(int dt, const void* x, const float* dy, float* dW, float* dbias, int N, int H, int W, int OC,
                       hipStream_t s);
 
+// stem backward in one pass (stem_bwd.hip): BatchNorm sums + the three pixel reductions dW is an affine function of
+bool stem_bwd_fusable(int S);
+int stem_bwd_part_floats();
+int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* ms, const float* mb, const float* mean,
+                    const float* istd, float* partials, long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s);   // returns rows
+int launch_stem_bwd_finalize(const float* partials, int nparts, const float* global_sums, double count, const float* gamma, const float* mean,
+                             const float* istd, float* dgamma, float* dbeta, float* dW, hipStream_t s);
+
 // ---------------------------------------------------------------- BatchNorm pieces
 // per-channel (sum, sumsq) partials over an NHWC tensor of T: out [nparts][2][C]; returns nparts
 int launch_chan_stats_nhwc(int dt, const void* y, long npix, int C, float* partials, hipStream_t s);
@@ -177,7 +185,7 @@ struct BnFinalizeArgs {
   float* mean; float* istd; float* scale; float* shift; float momentum, eps;
 };
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
-int launch_partial_rowsum(const float* partials, int nparts, int width, float* out, hipStream_t s);   // SyncBN: [nparts][width] -> [width]
+int launch_partial_rowsum(const float* partials, int nparts, int width, float* out, hipStream_t s, int row_stride = 0);   // SyncBN: [nparts][width (stride row_stride)] -> [width]
 // eval: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
 int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                           float* scale, float* shift, hipStream_t s);

@@ -19,6 +19,23 @@ template <typename T> __device__ __forceinline__ f32x4 mma_vec(const Vec16& a, c
 template <> __device__ __forceinline__ f32x4 mma_vec<bf16_t>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_bf16(a, b, c); }
 template <> __device__ __forceinline__ f32x4 mma_vec<float>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_f32v(a, b, c); }
 
+// pixel-major MFMA fragments out of a natural-layout [pixel][channel] LDS image (weight-gradient style reductions over pixels)
+template <typename T> struct FragOps;
+template <> struct FragOps<bf16_t> {
+  // lane (g = lane>>4, i = lane&15): 8 pixels = two 4-pixel blocks; lane supplies the address of pixel-row q = i>>2,
+  // channel quad p = i&3 of its group's block and receives channel i of the 4 pixels (ds_read_b64_tr_b16).
+  __device__ static __forceinline__ Vec16 load(const char* base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
+    Vec16 v;
+    v.w[0] = (uint32_t)(uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+    v.w[1] = (uint32_t)(uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+    v.w[2] = (uint32_t)(uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+    v.w[3] = (uint32_t)(uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+    return v;
+  }
+};
+
 __device__ __forceinline__ void tile_origin(const TileGeom& g, int tile, int seg, int& n, int& hq0) {
   if (g.tiles_per_img > 0) {
     n = tile / g.tiles_per_img;

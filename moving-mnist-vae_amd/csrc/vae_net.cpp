@@ -197,6 +197,12 @@ int Net::side_join(hipStream_t s) {
 }
 
 // measured: im2col + 1x1 weight gradient 0.39 ms, planar-G patch-tile path 0.42 ms (MMVAE_STEM_PLANAR=1)
+// MMVAE_STEM_FUSED=0 restores reduce -> apply -> im2col -> wgrad
+bool Net::stem_bwd_fused() const {
+  static const bool env = [] { const char* e = getenv("MMVAE_STEM_FUSED"); return !(e && e[0] == '0'); }();
+  return env && cfg.in_ch == 1 && stem_bwd_fusable(cfg.S);
+}
+
 static bool stem_im2col_path() {
   static const bool v = [] { const char* e = getenv("MMVAE_STEM_PLANAR"); return !(e && e[0] == '1'); }();
   return v;
@@ -228,10 +234,10 @@ bool Net::tail_fwd_fused() const {
 
 // SyncBN: sum the partial rows locally, let the host's collective sum the row over the ranks (stream-ordered), and hand the
 // finalize kernels that one row.  Two operand slots: the caller's stream and the side stream may both have one in flight.
-int Net::sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out) {
+int Net::sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out, int row_stride) {
   if (width > 1024) { set_error("sync_bn: %d statistics per BatchNorm > 1024", width); return MMVAE_ERR_UNSUPPORTED; }
   float* buf = reinterpret_cast<float*>(base + plan_.syncbuf) + (s == side_ ? 1024 : 0);
-  MM_TRY(launch_partial_rowsum(partials, nparts, width, buf, s));
+  MM_TRY(launch_partial_rowsum(partials, nparts, width, buf, s, row_stride));
   if (comm_) MM_TRY(comm_allreduce_sum(comm_, buf, width, s));
   else if (ar_fn_(buf, width, s, ar_user_) != 0) { set_error("sync_bn: the all-reduce callback failed"); return MMVAE_ERR_ARG; }
   *out = buf;
@@ -486,7 +492,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(side_fork(s));
     MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
     // the stem's im2col depends on the input image only: early, off the tail of the critical path
-    if (stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
+    if (!stem_bwd_fused() && stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
     pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / nt;
@@ -542,6 +548,25 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
     MM_TRY(run_up(B.cs, base, N, base + dyso, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     cur ^= 1;
+  }
+  // ---- stem: bn0 + relu backward and the 5x5 weight gradient
+  if (stem_bwd_fused()) {
+    // one pass over g and y0 (stem_bwd.hip): BatchNorm sums and the three pixel reductions dW is an affine function of; no dy
+    // tensor, no im2col, nothing waits on a grid-wide reduction except the 32-block finalize
+    const long npix = (long)N * H1 * W1;
+    const int np = launch_stem_bwd(dt(), base + P.g[cur], base + P.y0, base + P.x_t, bnf(bn0, base, 2), bnf(bn0, base, 3), bnf(bn0, base, 0),
+                                   bnf(bn0, base, 1), part, kPartialFloats, N, cfg.S, H1, W1, s);
+    MM_TRY(np);
+    const float* gsum = nullptr; double cnt = (double)npix;
+    if (sync_bn_on()) {
+      float* row = nullptr;
+      MM_TRY(sync_rows(base, part, np, 64, s, &row, stem_bwd_part_floats()));
+      gsum = row; cnt *= ar_world_;
+    }
+    MM_TRY(launch_stem_bwd_finalize(part, np, gsum, cnt, params + bn0.g_off, bnf(bn0, base, 0), bnf(bn0, base, 1), grads + bn0.g_off,
+                                    grads + bn0.b_off, grads + stem.off, s));
+    MM_TRY(side_join(s));
+    return MMVAE_OK;
   }
   // ---- stem: bn0 + relu backward, then the 5x5 weight gradient
   MM_TRY(side_wait_mark(1, s));    // the stem uses dy set 1 (block index -1): block 1's weight gradients read it last

@@ -111,11 +111,12 @@ class Net {
   // Last up-block forward as one kernel (join + tail conv, the joined activation is never stored); the backward then needs the
   // recomputing wgrad and the recomputing join backward.  MMVAE_TAIL_FWD_FUSED=0 restores join -> conv.
   bool tail_fwd_fused() const;
+  bool stem_bwd_fused() const;       // stem backward as one pass (stem_bwd.hip)
   // decoder_bwd leaves its weight gradients running on the side stream; encoder_bwd (or join()) orders them before the caller's stream
   bool defer_join_ = false;
   int (*ar_fn_)(float*, long long, void*, void*) = nullptr; void* ar_user_ = nullptr; int ar_world_ = 1;
   Comm* comm_ = nullptr;
-  int sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out);
+  int sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out, int row_stride = 0);
  public:
   void set_defer_join(bool v) { defer_join_ = v; }
   // SyncBN: fn sums a device f32 buffer over all ranks, ordered on the given stream; NULL = per-rank statistics
