@@ -167,10 +167,11 @@ int launch_tail_wgrad(int dt, const void* x, const float* dy, float* dW, float* 
 // stem backward in one pass (stem_bwd.hip): BatchNorm sums + the three pixel reductions dW is an affine function of
 bool stem_bwd_fusable(int S);
 int stem_bwd_part_floats();
-int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* ms, const float* mb, const float* mean,
-                    const float* istd, float* partials, long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s);   // returns rows
-int launch_stem_bwd_finalize(const float* partials, int nparts, const float* global_sums, double count, const float* gamma, const float* mean,
-                             const float* istd, float* dgamma, float* dbeta, float* dW, hipStream_t s);
+int launch_stem_gram(int dt, const void* x, float* scratch, long scratch_cap_floats, double* R, int N, int S, int Ho, int Wo, hipStream_t s);
+int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* ms, const float* mb, float* partials,
+                    long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s);   // returns rows
+int launch_stem_bwd_finalize(const float* partials, int nparts, const double* R, const float* w, const float* global_sums, double count,
+                             const float* gamma, const float* mean, const float* istd, float* dgamma, float* dbeta, float* dW, hipStream_t s);
 
 // ---------------------------------------------------------------- BatchNorm pieces
 // per-channel (sum, sumsq) partials over an NHWC tensor of T: out [nparts][2][C]; returns nparts

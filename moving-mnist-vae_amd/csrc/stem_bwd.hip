@@ -4,179 +4,195 @@
 // The stem needs no data gradient, only dW / dgamma / dbeta, and BatchNorm-backward is affine in its sums:
 //     dy = A * (gm - m1 - m2 * yhat),   gm = g * [y0*s + b > 0],  yhat = (y0 - mean) * istd,
 //     m1 = sum(gm) / count,  m2 = sum(gm * yhat) / count,  A = gamma * istd
-// so   dW[c][t] = sum_pix dy[c] * patch[t] = A[c] * (W1[c][t] - m2[c] * W2[c][t] - m1[c] * W3[t])
-// with W1 = sum gm (x) patch,  W2 = sum yhat (x) patch,  W3 = sum patch -- three pixel reductions that do NOT depend on
-// m1 / m2.  One kernel therefore produces the BatchNorm sums AND the three images (one MFMA reduction with 80 "channels":
-// gm | yhat | ones, against the 25 taps of the 5x5 patch gathered on the fly from an LDS copy of the image rows), and a
-// finalize kernel combines them.  Replaces bn_bwd_reduce + bn_bwd_apply + im2col + wgrad: 2.7 GB -> 0.7 GB of HBM
+// so   dW[c][t] = sum_pix dy[c] * patch[t] = A[c] * (W1[c][t] - m2[c] * istd[c] * (W2[c][t] - mean[c] * W3[t]) - m1[c] * W3[t])
+// with W1 = sum gm (x) patch,  W2 = sum y0 (x) patch,  W3 = sum patch -- three pixel reductions that do NOT depend on
+// m1 / m2.  W2 and W3 do not even depend on the gradient: y0 = w * patch, so W2 = w x R with R = sum patch (x) patch, the
+// 25 x 25 gram matrix of the batch's patches (W3 is its ones row) -- a 42 MB read of the image, off the critical path
+// ("gram" mode of the kernel, on the side stream).  On the critical path one pass over g and y0 ("grad" mode) produces the
+// BatchNorm sums and W1 (MFMA reduction over pixels against the 25 taps gathered on the fly from an LDS copy of the image
+// rows); a 32-block finalize combines everything in double precision.  Replaces bn_bwd_reduce + bn_bwd_apply + im2col + wgrad: 2.7 GB -> 0.7 GB of HBM
 // traffic per step at N = 5120, and nothing of it waits on a grid-wide reduction.
 //
-// Tile = rpt whole output rows of one image (<= 128 pixels); wave w owns the 32-pixel k-slice w of the tile.
-// LDS: [P tile 128 x 80 T][image patch prow x (W+4) f32]; the flush staging aliases the P tile.
+// Work unit = a 32-pixel slab (whole output rows of one image) owned by ONE wave: private LDS, no block barrier in the loop.
+// LDS per wave: [P slab 32 x 32 T][image patch prow x (W+8) f32]; the flush staging aliases the front.
+#include <stdlib.h>
+#include <string.h>
+
 #include "kernels.hpp"
 #include "tile_common.hpp"
 
 namespace mmvae {
 
-constexpr int kStemPA = 80;                        // P-tile channels: gm 0..31 | yhat 32..63 | ones 64 | zero 65..79
-constexpr int kStemPartFloats = 64 + kStemPA * 32; // per-block partial: S0[32] S1[32] | image [80][32]
+// MODE 0 ("grad"): P tile = gm (32 channels) built from g and y0; also the BatchNorm sums S0 = sum gm, S1 = sum gm * y0.
+// MODE 1 ("gram"): P tile = the im2col of the image itself (taps 0..24, a ones column at 25, zeros beyond): R = sum patch (x) patch
+//                  (row 25 = sum patch).  Reads only the image; runs off the critical path.
+constexpr int kStemPartFloats = 64 + 32 * 32;      // per-block partial: S0[32] S1[32] | image [32][32]
 
 struct StemBwdArgs {
   const void* g; const void* y0; const void* x;
-  const float* ms; const float* mb; const float* mean; const float* istd;
+  const float* ms; const float* mb;
   float* partials;
-  int N, H, W, Ho, Wo, rpt, tiles_per_img, ntiles, prow, pw;
+  int N, H, W, Ho, Wo, wshift, rps, slabs_per_img, nslabs, prow, pw;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void stem_bwd_kernel(StemBwdArgs a) {
+// Every WAVE streams its own 32-pixel slabs (rps whole output rows of one image) through wave-private LDS: no block barrier in
+// the loop, 16 independent software pipelines per CU.  Lane roles: staging = 16-byte vector `lane + 64k` of the slab (contiguous
+// in memory), fragments = the usual 16x16x32 / 16x16x4 maps over the slab's 32 pixels.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void stem_bwd_kernel(StemBwdArgs a) {
   constexpr int VE = Elem<T>::kVec, ES = sizeof(T);
-  constexpr int CV = 32 / VE;                      // 16-byte vectors per pixel of g / y0
-  constexpr int NS = 128 * CV / 256;               // staging slots per thread and tensor
-  constexpr int PPS = 256 / CV;                    // pixels per slot round
-  constexpr int PITCH = kStemPA * ES;
+  constexpr int CV = 32 / VE;                      // 16-byte vectors per pixel of g / y0 / the P slab
+  constexpr int NS = MODE == 0 ? 32 * CV / 64 : 1; // g / y0 vectors per lane and slab
+  constexpr int NXV = sizeof(T) == 2 ? 1 : 2;      // image vectors per lane and slab
+  constexpr int PITCH = 32 * ES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sP = smem;
-  float* sX = reinterpret_cast<float*>(sP + 128 * PITCH);
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, r = lane & 15;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
+  float* sC = reinterpret_cast<float*>(smem);                          // [2][32] mask coefficients (block-shared, read-only)
+  const int wave_bytes = 32 * PITCH + a.prow * a.pw * 4;
+  char* sP = smem + 256 + wv * wave_bytes;                             // this wave's P slab [32][32] T
+  float* sX = reinterpret_cast<float*>(sP + 32 * PITCH);               // this wave's image patch [prow][pw] f32, 4 halo columns a side
   const T* __restrict__ G = reinterpret_cast<const T*>(a.g);
   const T* __restrict__ Y = reinterpret_cast<const T*>(a.y0);
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
-  const int cv = t % CV, pp0 = t / CV;
-  float ms[VE], mb[VE], mean[VE], istd[VE], s0[VE], s1[VE];
+  if (MODE == 0 && t < 64) sC[t] = t < 32 ? a.ms[t] : a.mb[t - 32];
+  for (int i = lane; i < a.prow * a.pw; i += 64) sX[i] = 0.f;          // the halo columns stay zero
+  __syncthreads();
+  const int cv = lane % CV;
+  float s1[VE];                                     // sum gm * y0 (sum gm comes out of the MFMA: ones column of B)
 #pragma unroll
-  for (int j = 0; j < VE; ++j) {
-    ms[j] = a.ms[cv * VE + j]; mb[j] = a.mb[cv * VE + j]; mean[j] = a.mean[cv * VE + j]; istd[j] = a.istd[cv * VE + j];
-    s0[j] = 0.f; s1[j] = 0.f;
-  }
-  // image slots (tile-invariant): patch element idx = t + 256k -> (row, col)
-  const int nx = a.prow * a.W;
-  int xo[3], xg[3], xr[3];
+  for (int j = 0; j < VE; ++j) s1[j] = 0.f;
+  // image vector slots: vector idx = lane + 64k of the patch rows -> (row, column vector)
+  const int xvr = a.W / VE;                         // vectors per image row
+  int xrow[NXV], xcol[NXV];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int idx = t + 256 * k;
-    const int row = idx / a.W, col = idx - row * a.W;
-    xo[k] = row * a.pw + col + 2; xg[k] = row * a.W + col; xr[k] = idx < nx ? row : (1 << 28);
+  for (int k = 0; k < NXV; ++k) {
+    const int idx = lane + 64 * k;
+    xrow[k] = idx < a.prow * xvr ? idx / xvr : (1 << 28);
+    xcol[k] = (idx % xvr) * VE;
   }
-  // zero the P tile (its padding channels stay zero) and the image patch (its halo columns stay zero)
-  for (int i = t; i < 128 * PITCH / 16; i += 256) reinterpret_cast<Vec16*>(sP)[i] = Vec16{{0, 0, 0, 0}};
-  for (int i = t; i < a.prow * a.pw; i += 256) sX[i] = 0.f;
-  // fragment addressing of this lane (tile-invariant)
-  const int tile_pix = a.rpt * a.Wo;
-  int tapo[2];                                      // patch offset of tap 16tb + r, or -1
+  // fragment addressing (slab-invariant)
+  int tapo[2];                                      // patch offset of tap 16tb + r, or -1 (tap 25: the ones column -> sum of the P rows)
 #pragma unroll
   for (int tb = 0; tb < 2; ++tb) { const int tap = 16 * tb + r; tapo[tb] = tap < 25 ? (tap / 5) * a.pw + tap % 5 : -1; }
-  int offP[2], offX[8];
+  const float b_fill = r == 9 ? 1.f : 0.f;          // value of B column 16 + r outside the 25 taps (tb = 1 only)
+  auto pix_off = [&](int q) { return ((q >> a.wshift) * 2) * a.pw + (q & (a.Wo - 1)) * 2 + 2; };   // tap (0,0) of slab pixel q
+  int offP[2], offXb[2];
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) offP[b] = (32 * wv + 16 * b + 4 * gq + (r >> 2)) * PITCH + (r & 3) * 8;
+    for (int b = 0; b < 2; ++b) { offP[b] = (16 * b + 4 * gq + (r >> 2)) * PITCH + (r & 3) * 8; offXb[b] = pix_off(16 * b + 4 * gq); }
+  } else { offP[0] = offP[1] = 0; offXb[0] = offXb[1] = 0; }
+  // MODE 1: this lane builds half a row of the im2col slab: pixel lane >> 1, taps 16 * (lane & 1) ..
+  const int bq = lane >> 1, bh = lane & 1;
+  const int boff = pix_off(bq);
+  f32x4 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int q = 32 * wv + 16 * (j >> 2) + 4 * gq + (j & 3);
-      offX[j] = q < tile_pix ? (2 * (q / a.Wo)) * a.pw + 2 * (q % a.Wo) : 0;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int q = 32 * wv + 4 * j + gq;
-      offX[j] = q < tile_pix ? (2 * (q / a.Wo)) * a.pw + 2 * (q % a.Wo) : 0;
-    }
-    offP[0] = offP[1] = 0;
-  }
-  f32x4 acc[5][2];
-#pragma unroll
-  for (int ta = 0; ta < 5; ++ta) { acc[ta][0] = (f32x4){0, 0, 0, 0}; acc[ta][1] = (f32x4){0, 0, 0, 0}; }
+  for (int ta = 0; ta < 2; ++ta) { acc[ta][0] = (f32x4){0, 0, 0, 0}; acc[ta][1] = (f32x4){0, 0, 0, 0}; }
 
-  // ---- software pipeline: registers of the NEXT tile
-  Vec16 gv[NS], yv[NS];
-  float xv[3];
-  int nvalid_c = 0, r0_c = 0;
-  auto issue = [&](int tile) {
-    const int n = tile / a.tiles_per_img, h0 = (tile - n * a.tiles_per_img) * a.rpt;
-    nvalid_c = min(a.rpt, a.Ho - h0) * a.Wo;
+  // ---- software pipeline of this wave: registers of the NEXT slab
+  Vec16 gv[NS], yv[NS], xv[NXV];
+  int r0_c = 0;
+  auto issue = [&](int slab) {
+    const int n = slab / a.slabs_per_img, h0 = (slab - n * a.slabs_per_img) * a.rps;
     r0_c = 2 * h0 - 2;
-    const long base = (((long)n * a.Ho + h0) * a.Wo) * 32 + cv * VE;
+    if constexpr (MODE == 0) {
+      const long base = (((long)n * a.Ho + h0) * a.Wo) * 32 + lane * VE;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const int p = pp0 + k * PPS;
-      gv[k] = Vec16{{0, 0, 0, 0}}; yv[k] = Vec16{{0, 0, 0, 0}};
-      if (p < nvalid_c) {
-        gv[k] = *reinterpret_cast<const Vec16*>(G + base + (long)p * 32);
-        yv[k] = *reinterpret_cast<const Vec16*>(Y + base + (long)p * 32);
+      for (int k = 0; k < NS; ++k) {
+        gv[k] = *reinterpret_cast<const Vec16*>(G + base + k * 64 * VE);
+        yv[k] = *reinterpret_cast<const Vec16*>(Y + base + k * 64 * VE);
       }
     }
-    const T* xi = X + ((long)n * a.H + r0_c) * a.W;       // may point before the image: only in-range rows are read
+    const long xbase = ((long)n * a.H + r0_c) * a.W;      // may be negative: only in-range rows are read
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      xv[k] = 0.f;
-      if ((unsigned)(r0_c + xr[k]) < (unsigned)a.H) xv[k] = Elem<T>::load(xi + xg[k]);
+    for (int k = 0; k < NXV; ++k) {
+      xv[k] = Vec16{{0, 0, 0, 0}};
+      if ((unsigned)(r0_c + xrow[k]) < (unsigned)a.H) xv[k] = *reinterpret_cast<const Vec16*>(X + (xbase + (long)xrow[k] * a.W + xcol[k]));
     }
   };
   auto commit = [&]() {
+    if constexpr (MODE == 0) {
+      float ms[VE], mb[VE];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const int p = pp0 + k * PPS;
-      float fg[VE], fy[VE];
-      Elem<T>::unpack(gv[k], fg);
-      Elem<T>::unpack(yv[k], fy);
-      const bool ok = p < nvalid_c;
-#pragma unroll
-      for (int j = 0; j < VE; ++j) {
-        const float gm = (ok && fy[j] * ms[j] + mb[j] > 0.f) ? fg[j] : 0.f;
-        s0[j] += gm;
-        s1[j] += gm * fy[j];
-        fg[j] = gm;
-        fy[j] = ok ? (fy[j] - mean[j]) * istd[j] : 0.f;
+      for (int j = 0; j < VE; j += 4) {
+        const float4 u = *reinterpret_cast<const float4*>(sC + cv * VE + j), w = *reinterpret_cast<const float4*>(sC + 32 + cv * VE + j);
+        ms[j] = u.x; ms[j + 1] = u.y; ms[j + 2] = u.z; ms[j + 3] = u.w;
+        mb[j] = w.x; mb[j + 1] = w.y; mb[j + 2] = w.z; mb[j + 3] = w.w;
       }
-      *reinterpret_cast<Vec16*>(sP + p * PITCH + cv * 16) = Elem<T>::pack(fg);
-      *reinterpret_cast<Vec16*>(sP + p * PITCH + 32 * ES + cv * 16) = Elem<T>::pack(fy);
-      if (cv == 0) {
-        float one[VE];
 #pragma unroll
-        for (int j = 0; j < VE; ++j) one[j] = 0.f;
-        one[0] = ok ? 1.f : 0.f;
-        *reinterpret_cast<Vec16*>(sP + p * PITCH + 64 * ES) = Elem<T>::pack(one);
+      for (int k = 0; k < NS; ++k) {
+        float fg[VE], fy[VE];
+        Elem<T>::unpack(gv[k], fg);
+        Elem<T>::unpack(yv[k], fy);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          const float gm = (fy[j] * ms[j] + mb[j] > 0.f) ? fg[j] : 0.f;
+          s1[j] += gm * fy[j];
+          fg[j] = gm;
+        }
+        *reinterpret_cast<Vec16*>(sP + (lane + 64 * k) * 16) = Elem<T>::pack(fg);     // slab vector index == LDS vector index
       }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (xr[k] < (1 << 28)) sX[xo[k]] = xv[k];
+    for (int k = 0; k < NXV; ++k) {
+      if (xrow[k] < (1 << 28)) {
+        float f[VE];
+        Elem<T>::unpack(xv[k], f);
+        float* d = sX + xrow[k] * a.pw + 4 + xcol[k];
+#pragma unroll
+        for (int j = 0; j < VE; j += 4) *reinterpret_cast<float4*>(d + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+      }
+    }
   };
 
-#pragma unroll
-  for (int j = 0; j < VE; ++j) { asm volatile("" ::"v"(ms[j])); asm volatile("" ::"v"(mb[j])); asm volatile("" ::"v"(mean[j])); asm volatile("" ::"v"(istd[j])); }
-  int tile = blockIdx.x;
-  if (tile < a.ntiles) issue(tile);
-  for (; tile < a.ntiles; tile += gridDim.x) {
-    __syncthreads();                                // the previous tile's fragment reads are done (first: the zero fill)
+  const int gw = blockIdx.x * 4 + wv, gstride = gridDim.x * 4;
+  int slab = gw;
+  if (slab < a.nslabs) issue(slab);
+  for (; slab < a.nslabs; slab += gstride) {
     commit();
-    __syncthreads();
-    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);
+    if constexpr (MODE == 1) {
+      // im2col slab of the image itself: taps 16bh .. 16bh+15 of pixel bq (tap 25 = 1, taps > 25 = 0)
+      constexpr int NV = 16 / VE;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float f[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+          // bh is per lane: both constant tap sets are read, one is kept
+          const int tlo = v * VE + j, thi = 16 + v * VE + j;
+          const float lo = sX[boff + (tlo / 5) * a.pw + tlo % 5];
+          const float hi = thi < 25 ? sX[boff + (thi / 5) * a.pw + thi % 5] : (thi == 25 ? 1.f : 0.f);
+          f[j] = bh ? hi : lo;
+        }
+        *reinterpret_cast<Vec16*>(sP + bq * PITCH + (16 * bh + v * VE) * ES) = Elem<T>::pack(f);
+      }
+    }
+    if (slab + gstride < a.nslabs) issue(slab + gstride);
     if constexpr (sizeof(T) == 2) {
       Vec16 bf[2];
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb) {
         float f[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = tapo[tb] >= 0 ? sX[offX[j] + tapo[tb]] : 0.f;
+        for (int j = 0; j < 8; ++j) f[j] = tapo[tb] >= 0 ? sX[offXb[j >> 2] + 2 * (j & 3) + tapo[tb]] : b_fill;
         bf[tb] = Elem<bf16_t>::pack(f);
       }
 #pragma unroll
-      for (int ta = 0; ta < 5; ++ta) {
+      for (int ta = 0; ta < 2; ++ta) {
         const Vec16 af = FragOps<bf16_t>::load(sP, offP[0] + ta * 32, offP[1] + ta * 32);
         acc[ta][0] = mma_bf16(af, bf[0], acc[ta][0]);
         acc[ta][1] = mma_bf16(af, bf[1], acc[ta][1]);
       }
     } else {
-      // exact-f32 mode: 8 steps of v_mfma_f32_16x16x4_f32, step j covers pixels 32wv + 4j + gq
+      // exact-f32 mode: 8 steps of v_mfma_f32_16x16x4_f32, step j covers slab pixels 4j + gq
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int p = 32 * wv + 4 * j + gq;
+        const int p = 4 * j + gq;
+        const int po = pix_off(p);
         float bvv[2];
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) bvv[tb] = tapo[tb] >= 0 ? sX[offX[j] + tapo[tb]] : 0.f;
+        for (int tb = 0; tb < 2; ++tb) bvv[tb] = tapo[tb] >= 0 ? sX[po + tapo[tb]] : b_fill;
 #pragma unroll
-        for (int ta = 0; ta < 5; ++ta) {
+        for (int ta = 0; ta < 2; ++ta) {
           const float av = *reinterpret_cast<const float*>(sP + p * PITCH + (16 * ta + r) * 4);
           acc[ta][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv[0], acc[ta][0], 0, 0, 0);
           acc[ta][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv[1], acc[ta][1], 0, 0, 0);
@@ -185,11 +201,11 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_kernel(StemBwdArgs a) {
     }
   }
   // ---- flush: fixed summation order (wave 0, 1, 2, 3) -> bit-reproducible partials
-  // BatchNorm sums: lanes of a wave with equal channel vector first (xor shuffles), then the waves in order
+  // sum gm * y0: lanes of a wave with equal channel vector first (xor shuffles), then the waves in order
 #pragma unroll
   for (int j = 0; j < VE; ++j) {
 #pragma unroll
-    for (int o = CV; o < 64; o <<= 1) { s0[j] += __shfl_xor(s0[j], o, 64); s1[j] += __shfl_xor(s1[j], o, 64); }
+    for (int o = CV; o < 64; o <<= 1) s1[j] += __shfl_xor(s1[j], o, 64);
   }
   __syncthreads();
   float* sRed = reinterpret_cast<float*>(smem);
@@ -199,10 +215,10 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_kernel(StemBwdArgs a) {
     if (wv == w) {
       if (lane < CV) {
 #pragma unroll
-        for (int j = 0; j < VE; ++j) { sRed[lane * VE + j] += s0[j]; sRed[32 + lane * VE + j] += s1[j]; }
+        for (int j = 0; j < VE; ++j) sRed[32 + lane * VE + j] += s1[j];
       }
 #pragma unroll
-      for (int ta = 0; ta < 5; ++ta)
+      for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -210,13 +226,26 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_kernel(StemBwdArgs a) {
     }
   }
   __syncthreads();
+  if (t < 32) sRed[t] = sRed[64 + t * 32 + 25];   // S0[c] = image[c][25]
+  __syncthreads();
   float* dst = a.partials + (long)blockIdx.x * kStemPartFloats;
   for (int i = t; i < kStemPartFloats; i += 256) dst[i] = sRed[i];
+}
+
+// R[i] = sum over the gram kernel's partial rows, in double (row 25 = sum patch)
+__global__ __launch_bounds__(256) void stem_gram_sum_kernel(const float* __restrict__ partials, int nparts, double* __restrict__ R) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per element, 0 .. 1023
+  double s = 0.0;
+  for (int p = lane; p < nparts; p += 64) s += (double)partials[(long)p * kStemPartFloats + 64 + i];
+  s = wave_sum_d(s);
+  if (lane == 0) R[i] = s;
 }
 
 // ---------------------------------------------------------------- finalize: one block per stem channel
 struct StemBwdFinArgs {
   const float* partials; int nparts;
+  const double* R;               // [32][32] patch gram matrix of the batch; row 25 = sum patch
+  const float* w;                // stem weights [32][25] f32 (W2 = w x R: sum y0 (x) patch without reading y0 again)
   const float* global_sums;      // SyncBN: [2][32] sums over the global batch (coefficients); NULL: the local sums
   double count;                  // pixels behind the sums the coefficients use
   const float* gamma; const float* mean; const float* istd;
@@ -225,8 +254,12 @@ struct StemBwdFinArgs {
 
 __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(StemBwdFinArgs a) {
   __shared__ double sB[2][4];
-  __shared__ double sW[3][8][32];
+  __shared__ double sW[8][32];
+  __shared__ double sR[26 * 32];
+  __shared__ float sw[25];
   const int c = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < 26 * 32; i += 256) sR[i] = a.R[i];
+  if (t < 25) sw[t] = a.w[c * 25 + t];
   double b0 = 0.0, b1 = 0.0;
   for (int p = t; p < a.nparts; p += 256) {
     const float* row = a.partials + (long)p * kStemPartFloats;
@@ -234,13 +267,19 @@ __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(StemBwdFinArgs a
   }
   b0 = wave_sum_d(b0); b1 = wave_sum_d(b1);
   if ((t & 63) == 0) { sB[0][t >> 6] = b0; sB[1][t >> 6] = b1; }
+  // W1[c][tap]: 8 part-lanes per tap, 8 independent loads in flight each
   const int pl = t >> 5, tap = t & 31;
-  double w1 = 0.0, w2 = 0.0, w3 = 0.0;
-  for (int p = pl; p < a.nparts; p += 8) {
-    const float* img = a.partials + (long)p * kStemPartFloats + 64;
-    w1 += (double)img[c * 32 + tap]; w2 += (double)img[(32 + c) * 32 + tap]; w3 += (double)img[64 * 32 + tap];
+  const float* src = a.partials + 64 + c * 32 + tap;
+  double w1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w1[k] = 0.0;
+  int p = pl;
+  for (; p + 56 < a.nparts; p += 64) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w1[k] += (double)src[(long)(p + 8 * k) * kStemPartFloats];
   }
-  sW[0][pl][tap] = w1; sW[1][pl][tap] = w2; sW[2][pl][tap] = w3;
+  for (; p < a.nparts; p += 8) w1[0] += (double)src[(long)p * kStemPartFloats];
+  sW[pl][tap] = ((w1[0] + w1[1]) + (w1[2] + w1[3])) + ((w1[4] + w1[5]) + (w1[6] + w1[7]));
   __syncthreads();
   const double S0 = (sB[0][0] + sB[0][1]) + (sB[0][2] + sB[0][3]), S1 = (sB[1][0] + sB[1][1]) + (sB[1][2] + sB[1][3]);
   const double mean = a.mean[c], istd = a.istd[c], g = a.gamma ? a.gamma[c] : 1.0;
@@ -253,44 +292,75 @@ __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(StemBwdFinArgs a
   if (a.global_sums) { G0 = a.global_sums[c]; sgy = istd * ((double)a.global_sums[32 + c] - mean * G0); }
   const double m1 = G0 / a.count, m2 = sgy / a.count, A = g * istd;
   if (t < 25) {
-    double v1 = 0.0, v2 = 0.0, v3 = 0.0;
-    for (int q = 0; q < 8; ++q) { v1 += sW[0][q][t]; v2 += sW[1][q][t]; v3 += sW[2][q][t]; }
-    a.dW[c * 25 + t] += (float)(A * (v1 - m2 * v2 - m1 * v3));
+    double v1 = 0.0;
+    for (int q = 0; q < 8; ++q) v1 += sW[q][t];
+    double v2 = 0.0;                                   // sum_pix y0[c] * patch[t] = sum_t' w[c][t'] * R[t'][t]
+    for (int u = 0; u < 25; ++u) v2 += (double)sw[u] * sR[u * 32 + t];
+    const double v3 = sR[25 * 32 + t];
+    a.dW[c * 25 + t] += (float)(A * (v1 - m2 * istd * (v2 - mean * v3) - m1 * v3));
   }
 }
 
-bool stem_bwd_fusable(int S) { return S >= 9 && S <= 64; }
+// 32-pixel slabs of whole output rows: the output width S/2 must divide 32; image rows are read as 16-byte vectors
+bool stem_bwd_fusable(int S) { return S == 64 || S == 32 || S == 16; }
 
 int stem_bwd_part_floats() { return kStemPartFloats; }
 
-// Returns the number of partial rows (> 0) or an error.  partials: rows * stem_bwd_part_floats() floats.
-int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* ms, const float* mb, const float* mean,
-                    const float* istd, float* partials, long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s) {
-  if (!stem_bwd_fusable(S) || Wo > 128 || Wo < 1) { set_error("stem_bwd: image size %d unsupported", S); return MMVAE_ERR_UNSUPPORTED; }
-  StemBwdArgs a;
-  a.g = g; a.y0 = y0; a.x = x; a.ms = ms; a.mb = mb; a.mean = mean; a.istd = istd; a.partials = partials;
+static int stem_geom(StemBwdArgs& a, int dt, int N, int S, int Ho, int Wo) {
+  if (!stem_bwd_fusable(S) || Wo * 2 != S || Ho != Wo) { set_error("stem_bwd: image size %d unsupported", S); return MMVAE_ERR_UNSUPPORTED; }
   a.N = N; a.H = S; a.W = S; a.Ho = Ho; a.Wo = Wo;
-  a.rpt = 128 / Wo; if (a.rpt > Ho) a.rpt = Ho; if (a.rpt < 1) a.rpt = 1;
-  a.tiles_per_img = (Ho + a.rpt - 1) / a.rpt;
-  a.ntiles = N * a.tiles_per_img;
-  a.prow = 2 * a.rpt + 3; a.pw = S + 4;
-  if (a.prow * S > 768) { set_error("stem_bwd: patch of %d x %d exceeds the staging slots", a.prow, S); return MMVAE_ERR_UNSUPPORTED; }
-  int gx = 512;
-  if (gx > a.ntiles) gx = a.ntiles;
+  a.wshift = 0; while ((1 << a.wshift) < Wo) ++a.wshift;
+  a.rps = 32 / Wo;
+  a.slabs_per_img = Ho / a.rps;
+  a.nslabs = N * a.slabs_per_img;
+  a.prow = 2 * a.rps + 3; a.pw = S + 8;
+  const int ve = dt == DT_F32 ? 4 : 8;
+  if (a.prow * (S / ve) > 64 * (dt == DT_F32 ? 2 : 1)) { set_error("stem_bwd: patch of %d x %d exceeds the staging slots", a.prow, S); return MMVAE_ERR_UNSUPPORTED; }
+  return MMVAE_OK;
+}
+static size_t stem_lds(const StemBwdArgs& a, int dt) {
+  const size_t lds = 256 + 4 * ((size_t)32 * 32 * dtype_size(dt) + (size_t)a.prow * a.pw * 4);
+  return lds > (size_t)kStemPartFloats * 4 ? lds : (size_t)kStemPartFloats * 4;
+}
+
+// Patch gram matrix of the batch (input only): scratch = rows * stem_bwd_part_floats() floats, R = 1024 doubles.
+int launch_stem_gram(int dt, const void* x, float* scratch, long scratch_cap_floats, double* R, int N, int S, int Ho, int Wo, hipStream_t s) {
+  StemBwdArgs a; memset(&a, 0, sizeof(a));
+  const int rc0 = stem_geom(a, dt, N, S, Ho, Wo);
+  if (rc0 < 0) return rc0;
+  a.x = x; a.partials = scratch;
+  int gx = 1024;
+  if (gx * 4 > a.nslabs) gx = (a.nslabs + 3) / 4;
+  if ((long)gx * kStemPartFloats > scratch_cap_floats) gx = (int)(scratch_cap_floats / kStemPartFloats);
+  if (gx < 1) { set_error("stem_gram: scratch too small"); return MMVAE_ERR_WORKSPACE; }
+  if (dt == DT_F32) hipLaunchKernelGGL((stem_bwd_kernel<float, 1>), dim3(gx), dim3(256), stem_lds(a, dt), s, a);
+  else hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 1>), dim3(gx), dim3(256), stem_lds(a, dt), s, a);
+  int rc = check_launch("stem_gram");
+  if (rc) return rc;
+  hipLaunchKernelGGL(stem_gram_sum_kernel, dim3(256), dim3(256), 0, s, scratch, gx, R);
+  return check_launch("stem_gram_sum");
+}
+
+// Returns the number of partial rows (> 0) or an error.  partials: rows * stem_bwd_part_floats() floats.
+int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* ms, const float* mb, float* partials,
+                    long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s) {
+  StemBwdArgs a; memset(&a, 0, sizeof(a));
+  const int rc0 = stem_geom(a, dt, N, S, Ho, Wo);
+  if (rc0 < 0) return rc0;
+  a.g = g; a.y0 = y0; a.x = x; a.ms = ms; a.mb = mb; a.partials = partials;
+  int gx = 1024;
+  if (gx * 4 > a.nslabs) gx = (a.nslabs + 3) / 4;
   if ((long)gx * kStemPartFloats > partials_cap_floats) gx = (int)(partials_cap_floats / kStemPartFloats);
   if (gx < 1) { set_error("stem_bwd: partials buffer too small"); return MMVAE_ERR_WORKSPACE; }
-  const size_t es = dtype_size(dt);
-  const size_t lds = (size_t)128 * kStemPA * es + (size_t)a.prow * a.pw * 4;
-  const size_t need = lds > (size_t)kStemPartFloats * 4 ? lds : (size_t)kStemPartFloats * 4;
-  if (dt == DT_F32) hipLaunchKernelGGL((stem_bwd_kernel<float>), dim3(gx), dim3(256), need, s, a);
-  else hipLaunchKernelGGL((stem_bwd_kernel<bf16_t>), dim3(gx), dim3(256), need, s, a);
+  if (dt == DT_F32) hipLaunchKernelGGL((stem_bwd_kernel<float, 0>), dim3(gx), dim3(256), stem_lds(a, dt), s, a);
+  else hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 0>), dim3(gx), dim3(256), stem_lds(a, dt), s, a);
   const int rc = check_launch("stem_bwd");
   return rc ? rc : gx;
 }
 
-int launch_stem_bwd_finalize(const float* partials, int nparts, const float* global_sums, double count, const float* gamma, const float* mean,
-                             const float* istd, float* dgamma, float* dbeta, float* dW, hipStream_t s) {
-  StemBwdFinArgs a{partials, nparts, global_sums, count, gamma, mean, istd, dgamma, dbeta, dW};
+int launch_stem_bwd_finalize(const float* partials, int nparts, const double* R, const float* w, const float* global_sums, double count,
+                             const float* gamma, const float* mean, const float* istd, float* dgamma, float* dbeta, float* dW, hipStream_t s) {
+  StemBwdFinArgs a{partials, nparts, R, w, global_sums, count, gamma, mean, istd, dgamma, dbeta, dW};
   hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(32), dim3(256), 0, s, a);
   return check_launch("stem_bwd_finalize");
 }

@@ -142,6 +142,8 @@ const Plan& Net::plan(int N) {
   P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
   P.wscratch = take((long)kWgradScratchBytes);
+  P.stem_R = take(1024 * 8);
+  P.stem_gram = take(1024L * stem_bwd_part_floats() * 4);
   P.bytes = (size_t)cur;
   plan_ = P;
   return plan_;
@@ -492,6 +494,10 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(side_fork(s));
     MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
     // the stem's im2col depends on the input image only: early, off the tail of the critical path
+    // the stem's input-only work (patch gram matrix / im2col) early, off the tail of the critical path
+    if (stem_bwd_fused())
+      MM_TRY(launch_stem_gram(dt(), base + P.x_t, reinterpret_cast<float*>(base + P.stem_gram), 1024L * stem_bwd_part_floats(),
+                              reinterpret_cast<double*>(base + P.stem_R), N, cfg.S, H1, W1, wgrad_stream(s)));
     if (!stem_bwd_fused() && stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
@@ -554,8 +560,8 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // one pass over g and y0 (stem_bwd.hip): BatchNorm sums and the three pixel reductions dW is an affine function of; no dy
     // tensor, no im2col, nothing waits on a grid-wide reduction except the 32-block finalize
     const long npix = (long)N * H1 * W1;
-    const int np = launch_stem_bwd(dt(), base + P.g[cur], base + P.y0, base + P.x_t, bnf(bn0, base, 2), bnf(bn0, base, 3), bnf(bn0, base, 0),
-                                   bnf(bn0, base, 1), part, kPartialFloats, N, cfg.S, H1, W1, s);
+    const int np = launch_stem_bwd(dt(), base + P.g[cur], base + P.y0, base + P.x_t, bnf(bn0, base, 2), bnf(bn0, base, 3), part, kPartialFloats,
+                                   N, cfg.S, H1, W1, s);
     MM_TRY(np);
     const float* gsum = nullptr; double cnt = (double)npix;
     if (sync_bn_on()) {
@@ -563,9 +569,10 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
       MM_TRY(sync_rows(base, part, np, 64, s, &row, stem_bwd_part_floats()));
       gsum = row; cnt *= ar_world_;
     }
-    MM_TRY(launch_stem_bwd_finalize(part, np, gsum, cnt, params + bn0.g_off, bnf(bn0, base, 0), bnf(bn0, base, 1), grads + bn0.g_off,
-                                    grads + bn0.b_off, grads + stem.off, s));
-    MM_TRY(side_join(s));
+    MM_TRY(side_join(s));            // the gram matrix (side stream) and every weight gradient of this pass
+    MM_TRY(launch_stem_bwd_finalize(part, np, reinterpret_cast<const double*>(base + P.stem_R), params + stem.off, gsum, cnt,
+                                    params + bn0.g_off, bnf(bn0, base, 0), bnf(bn0, base, 1), grads + bn0.g_off, grads + bn0.b_off,
+                                    grads + stem.off, s));
     return MMVAE_OK;
   }
   // ---- stem: bn0 + relu backward, then the 5x5 weight gradient

@@ -41,6 +41,7 @@ struct Plan {
   long g[2], dy1[2], dy2[2], dys[2], da1, dh;            // backward temporaries (dy*: two sets, alternating per block, so the
                                                          // weight gradients on the side stream may lag one block behind)
   long wscratch;                                         // [tap][a][b] reduction image of the largest weight gradient
+  long stem_R, stem_gram;                                // stem backward: patch gram matrix (1024 doubles) and its per-block partials
   long enc_ws_end;
 };
 
