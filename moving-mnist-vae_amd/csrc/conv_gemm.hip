@@ -340,6 +340,7 @@ static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
 static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   static const int enabled = [] { const char* e = getenv("MMVAE_PATCH"); return e ? atoi(e) : 1; }();
   if (!enabled || a.Cout > 64 || a.Cin > 256) return 0;
+  if (a.x2 && (a.x_planar || a.y_planes || a.accumulate || out_dt != dt || a.Cin2 % (dt == DT_F32 ? 4 : 8) != 0 || a.Cin2 > 128 || a.Cout > 32)) return 0;
   if ((long)a.N * a.Ho * a.Wo * (a.y_planes ? a.y_planes : a.Cout) >= (1L << 30)) return 0;     // 32-bit output offsets
   if (!a.x_planar && (long)a.N * a.Hi * a.Wi * a.Cin * (long)dtype_size(dt) >= (1L << 31)) return 0;   // buffer-load range
   const int VE = dt == DT_F32 ? 4 : 8;
@@ -374,6 +375,17 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   }
   if ((size_t)b.w_vecs * 16 > 40 * 1024) return 0;
   for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
+  b.x2_phase = -1;
+  if (a.x2) {
+    // the second source lives on the q grid: its phase must span the whole q grid
+    for (int p = 0; p < a.nphase; ++p)
+      if (a.phases[p].ph == a.x2_ph && a.phases[p].pw == a.x2_pw && a.phases[p].Hq == Hq && a.phases[p].Wq == Wq) b.x2_phase = p;
+    if (b.x2_phase < 0) return 0;
+    if ((long)a.N * Hq * Wq * a.Cin2 * (long)dtype_size(dt) >= (1L << 31)) return 0;
+    b.x2 = a.x2; b.w2 = a.w2; b.Cin2 = a.Cin2;
+    b.kvp2 = (a.Cin2 / VE + 3) & ~3;
+    b.x2_bytes = (unsigned)((long)a.N * Hq * Wq * a.Cin2 * (long)dtype_size(dt));
+  }
   // tile size: 128 q-pixels, or 256 / 512 (whole rows, power-of-two width >= 16) for the 16- and 32-channel layers:
   // bigger tiles amortise barriers, tile decode and the patch halo
   static const int sub_env = [] { const char* e = getenv("MMVAE_PATCH_SUB"); return e ? atoi(e) : 0; }();
@@ -408,6 +420,11 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
     // staging buffer of one wave: NCHW planes, or channel-quad planes [npt][SO][ct16][4] of (16 q x 4 channels + 16 B skew)
     b.out_wave_bytes = !b.uni ? 0 : (int)(a.y_planes ? (size_t)a.y_planes * b.npt * 16 * 4 : (size_t)b.npt * a.SO * ct16 * 4 * (16 * 4 * out_es + 16));
     b.out_wave_bytes = (b.out_wave_bytes + 15) & ~15;
+    if (a.x2) {
+      if (b.npt != 2) continue;                                                 // second source: 128-pixel tiles only
+      b.x2_slots = (b.g.segs * b.g.qr * Wq * (a.Cin2 / VE) + 255) / 256;
+      if (b.x2_slots > 4) continue;
+    }
     lds = patch_conv_lds_bytes(b, dt);
     slots = patch_conv_slots(b, dt);
     ok = lds <= (sub > 1 ? 48 * 1024 : kV2MaxLds) && slots <= 12;
@@ -432,6 +449,11 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   b.xcd_walk = conv_xcd_walk();
   { const char* e = getenv("MMVAE_DBG"); b.dbg = e ? atoi(e) : 0; }
   b.x_bytes = a.x_planar ? 0u : (unsigned)((long)a.N * a.Hi * a.Wi * a.Cin * (long)dtype_size(dt));
+  if (a.x2) {
+    if (ct16 > 2) return 0;
+    patch_conv_x2_carve(b, dt);
+    if (occ > 2 && ct16 == 1 && slots <= 4) { occ = occ_regs - 1 > 1 ? occ_regs - 1 : 1; gx = 256 * occ; if (gx > b.g.ntiles) gx = b.g.ntiles; if (gx > kGatherMaxGridX) gx = kGatherMaxGridX; if (gx >= 8) gx &= ~7; }
+  }
   return launch_patch_conv(dt, out_dt, b, gx, s);
 }
 
@@ -480,8 +502,30 @@ static int try_deep(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   return launch_deep_conv(dt, out_dt, b, gx, s);
 }
 
+// the second source as its own accumulate launch (shapes the patch-tile kernel does not merge)
+static int launch_x2_separately(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
+  GatherArgs b; memset(&b, 0, sizeof(b));
+  int Hq = 0, Wq = 0;
+  for (int p = 0; p < a.nphase; ++p) if (a.phases[p].ph == a.x2_ph && a.phases[p].pw == a.x2_pw) { Hq = a.phases[p].Hq; Wq = a.phases[p].Wq; }
+  if (Hq <= 0) { set_error("gather_gemm: the second source's phase (%d,%d) is not part of the launch", a.x2_ph, a.x2_pw); return MMVAE_ERR_ARG; }
+  b.x = a.x2; b.w = a.w2; b.y = a.y; b.accumulate = 1;
+  b.N = a.N; b.Hi = Hq; b.Wi = Wq; b.Cin = a.Cin2; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = 1; b.SO = a.SO;
+  b.nphase = 1; b.phases[0] = Phase{a.x2_ph, a.x2_pw, Hq, Wq, 1, 0, 0}; b.taps[0] = Tap{0, 0};
+  return launch_gather_gemm(dt, out_dt, b, s);
+}
+
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
+  if (a.x2) {
+    static const bool merge = [] { const char* e = getenv("MMVAE_X2_MERGE"); return !(e && e[0] == '0'); }();
+    int rc = (merge && !conv_force_v1()) ? try_patch(dt, out_dt, a, s) : 0;
+    if (rc != 0) return rc;
+    GatherArgs m = a; m.x2 = nullptr; m.w2 = nullptr; m.Cin2 = 0;
+    rc = launch_gather_gemm(dt, out_dt, m, s);
+    if (rc < 0) return rc;
+    const int rc2 = launch_x2_separately(dt, out_dt, a, s);
+    return rc2 < 0 ? rc2 : rc;
+  }
   if (a.Cin % VE != 0 || a.Cout % 4 != 0 || a.nphase < 1 || a.nphase > kMaxPhases) {
     set_error("gather_gemm: unsupported Cin=%d Cout=%d nphase=%d", a.Cin, a.Cout, a.nphase);
     return MMVAE_ERR_UNSUPPORTED;

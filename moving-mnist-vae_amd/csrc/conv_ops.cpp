@@ -64,9 +64,10 @@ int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t
 }
 
 int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
-                const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s) {
+                const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s, const SecondSrc& x2) {
   GatherArgs a; std::memset(&a, 0, sizeof(a));
   if (g.k * g.k > kMaxTaps) { set_error("run_down: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
+  if (x2.x2) { a.x2 = x2.x2; a.w2 = x2.w2; a.Cin2 = x2.Cin2; a.x2_ph = 0; a.x2_pw = 0; }
   a.x = L; a.w = packed; a.y = S;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hl; a.Wi = Wl; a.Cin = g.D1; a.Ho = Hs; a.Wo = Ws; a.Cout = g.D0; a.SI = g.s; a.SO = 1;
@@ -78,9 +79,10 @@ int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N
 }
 
 int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
-              const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s) {
+              const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s, const SecondSrc& x2) {
   if (g.s > 2 || g.k * g.k > kMaxTaps) { set_error("run_up: k=%d s=%d unsupported", g.k, g.s); return MMVAE_ERR_UNSUPPORTED; }
   GatherArgs a; std::memset(&a, 0, sizeof(a));
+  if (x2.x2) { a.x2 = x2.x2; a.w2 = x2.w2; a.Cin2 = x2.Cin2; a.x2_ph = 0; a.x2_pw = 0; }
   a.x = S; a.w = packed; a.y = L;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hs; a.Wi = Ws; a.Cin = g.D0; a.Ho = Hl; a.Wo = Wl; a.Cout = g.D1; a.SI = 1; a.SO = g.s;

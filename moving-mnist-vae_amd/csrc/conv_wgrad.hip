@@ -103,8 +103,19 @@ size_t patch_conv_lds_bytes(const PatchArgs& a, int dt) {
   const int VE = dt == DT_F32 ? 4 : 8;
   const int cin_vecs = a.Cin / VE;
   int ct16 = (a.Cout + 15) / 16; if (ct16 == 3) ct16 = 4;
-  return (size_t)a.w_vecs * 16 + (size_t)a.g.segs * a.g.PR * a.g.PW * cin_vecs * 16 + (size_t)a.koff_total * 4 + (size_t)8 * ct16 * 16 * 4 +
-         (a.uni ? (size_t)4 * a.out_wave_bytes : 0);
+  size_t b = (size_t)a.w_vecs * 16 + (size_t)a.g.segs * a.g.PR * a.g.PW * cin_vecs * 16 + (size_t)a.koff_total * 4 + (size_t)8 * ct16 * 16 * 4 +
+             (a.uni ? (size_t)4 * a.out_wave_bytes : 0);
+  b = (b + 15) & ~(size_t)15;
+  if (a.x2) b += (size_t)ct16 * 16 * (a.kvp2 + 1) * 16 + ((size_t)a.g.segs * a.g.qr * a.g.Wq * (a.Cin2 / VE) + 8) * 16;
+  return b;
+}
+// Vec16 offsets (from the start of LDS) of the second source's weights / tile: right behind everything else
+void patch_conv_x2_carve(PatchArgs& a, int dt) {
+  PatchArgs z = a; z.x2 = nullptr;
+  const size_t base = patch_conv_lds_bytes(z, dt);
+  int ct16 = (a.Cout + 15) / 16; if (ct16 == 3) ct16 = 4;
+  a.w2_vec0 = (int)(base / 16);
+  a.x2_vec0 = a.w2_vec0 + ct16 * 16 * (a.kvp2 + 1);
 }
 
 int patch_conv_slots(const PatchArgs& a, int dt) {

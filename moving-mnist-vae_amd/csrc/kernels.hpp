@@ -31,6 +31,11 @@ struct GatherArgs {
   int x_planar, x_planes;  // 1: x is planar f32 [N][x_planes][Hi][Wi], 2: planar T; staged as Cin=16 channels, zero padded
   int dbg;                 // developer switches (MMVAE_DBG): bit0 skip global loads, bit1 skip stores, bit2 skip MFMA
   int y_planes;            // >0: y is NCHW f32 [N][y_planes][Ho][Wo] (Cout = 16 padded GEMM rows; stats rows have y_planes channels)
+  // optional SECOND source (patch-tile kernel only; launch_gather_gemm returns MMVAE_ERR_UNSUPPORTED when it cannot take it):
+  // y[q-pixel of phase (x2_ph, x2_pw)] += sum_c2 x2[n, hq, wq, c2] * w2[co][c2] -- a 1x1 convolution of a tensor that lives on the
+  // q grid itself ([N][Hq][Wq][Cin2] of T, no halo).  Merges the two data gradients that meet at a residual block's input
+  // (3x3 / 4x4 main path + 1x1 shortcut) into one kernel: no read-modify-write of the sum.
+  const void* x2; const void* w2; int Cin2, x2_ph, x2_pw;
 };
 // out_dt: dtype of y (may be DT_F32 while x/w are bf16).  Returns the number of stats partial rows (>0) or an error (<0).
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s);
@@ -116,8 +121,11 @@ struct PatchArgs {
   int phase_of[4];             // uni: phase index of output sub-position (ph, pw) = [ph*SO + pw]
   int dbg;                     // developer switches (MMVAE_DBG): 1 skip loads, 2 skip LDS commit, 4 skip MFMA+epilogue, 8 skip stores
   unsigned x_bytes;            // size of x in bytes (< 2^31): buffer-load range for the NHWC staging
+  // second source (see GatherArgs): [N][Hq][Wq][Cin2] on the q grid, weights [Cout][Cin2], added into phase x2_phase
+  const void* x2; const void* w2; int Cin2, x2_phase, kvp2, w2_vec0, x2_vec0, x2_slots; unsigned x2_bytes;
 };
 size_t patch_conv_lds_bytes(const PatchArgs& a, int dt);
+void patch_conv_x2_carve(PatchArgs& a, int dt);
 int patch_conv_slots(const PatchArgs& a, int dt);
 int launch_patch_conv(int dt, int out_dt, const PatchArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
 // ---- deep-layer implicit GEMM (conv_deep.inc): resident unpadded patch + streamed weights, 512 threads

@@ -163,14 +163,20 @@ int Net::pack_up(const ConvW& w, const float* params, char* base, hipStream_t s)
   return op_pack_up(dt(), geom(w), params + w.off, base + plan_.packed + w.packU * (long)esz(), s);
 }
 int Net::run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
-                  const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s) {
+                  const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s,
+                  const ConvW* w2, const void* x2) {
+  SecondSrc q;
+  if (w2) { q.x2 = x2; q.w2 = base + plan_.packed + w2->packU * (long)esz(); q.Cin2 = w2->D0; }
   return op_run_down(dt(), out_dt, geom(w), base + plan_.packed + w.packD * (long)esz(), N, L, Hl, Wl, S, Hs, Ws, pro_s, pro_b, relu,
-                     stats, accumulate, s);
+                     stats, accumulate, s, q);
 }
 int Net::run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
-                const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s) {
+                const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s,
+                const ConvW* w2, const void* x2) {
+  SecondSrc q;
+  if (w2) { q.x2 = x2; q.w2 = base + plan_.packed + w2->packU * (long)esz(); q.Cin2 = w2->D0; }
   return op_run_up(dt(), geom(w), base + plan_.packed + w.packU * (long)esz(), N, S, Hs, Ws, L, Hl, Wl, pro_s, pro_b, relu, stats,
-                   accumulate, s);
+                   accumulate, s, q);
 }
 hipStream_t Net::wgrad_stream(hipStream_t s) {
   if (side_state_ == 0) {
@@ -551,8 +557,9 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(side_fork(s));
     MM_TRY(run_wgrad(B.c1, N, base + dy1o, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(side_mark(i));
-    MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
-    MM_TRY(run_up(B.cs, base, N, base + dyso, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
+    // one kernel: the 1x1 stride-2 shortcut's data gradient is a second source of the 3x3 conv's (phase (0,0)); no read-modify-write
+    MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s, &B.cs,
+                  base + dyso));
     cur ^= 1;
   }
   // ---- stem: bn0 + relu backward and the 5x5 weight gradient
@@ -806,8 +813,9 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(run_wgrad(B.c1, N, base + P.dy1[ds], B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(side_mark(i));
     // d_xin = dgrad(conv1)(dy1) + dgrad(upsample)(dys)
-    MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
-    MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, dt(), s));
+    // one kernel: the 1x1 conv's data gradient (dy1, already on this block's input grid) is a second source of the shortcut's
+    MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s,
+                    &B.c1, base + P.dy1[ds]));
     cur ^= 1;
   }
   // ---- decoder stem

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "comm.hpp"
+#include "conv_ops.hpp"
 #include "kernels.hpp"
 
 namespace mmvae {
@@ -103,10 +104,13 @@ class Net {
   int packs_dec_bwd(const float* params, char* base, bool need_denc, hipStream_t s);
   int pack_down(const ConvW& w, const float* params, char* base, hipStream_t s);
   int pack_up(const ConvW& w, const float* params, char* base, hipStream_t s);
+  // w2 / x2 (optional): the 1x1 conv whose "up" form over x2 (a tensor on the small-side grid) is added in the same kernel
   int run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
-               const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s);
+               const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s,
+               const ConvW* w2 = nullptr, const void* x2 = nullptr);
   int run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
-             const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s);
+             const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s,
+             const ConvW* w2 = nullptr, const void* x2 = nullptr);
   int run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
                 const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s);
   // Last up-block forward as one kernel (join + tail conv, the joined activation is never stored); the backward then needs the
