@@ -34,6 +34,7 @@ DATA_MEAN, DATA_STD, P_ON = 0.0521, 0.2222, 0.0521
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 TRAIN_BYTES_PER_FRAME = 3.40e6  # ideal-fusion bf16 activation traffic of one train step, per frame
 TRAIN_FLOP_PER_FRAME = 227409920  # z=128, SURVEY.md section 8(d)
+C4_TRAIN_FLOP_PER_FRAME = {512: 409862144}   # tools/count_flops.py: z=512, 2 blocks per stage (forward 137 166 848)
 
 
 def synthetic_clips(clips, seed, device):
@@ -252,8 +253,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--clips", type=int, default=256, help="clips (of 20 frames) per GPU per step")
-    ap.add_argument("--z", type=int, default=128)
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2 (default, the headline): BASELINE configs[1], reference depth, z=128, 256 clips; c4: BASELINE configs[3], the deeper "
+                         "build-defined variant (2 residual blocks per stage), z=512, 512 clips")
+    ap.add_argument("--clips", type=int, default=None, help="clips (of 20 frames) per GPU per step (default: 256 for c2, 512 for c4)")
+    ap.add_argument("--z", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -262,6 +266,11 @@ def main():
                     help="gradient exchange through torch.distributed's nccl(=RCCL) backend, or through the library's own RCCL "
                          "communicator (mmvae_comm_*)")
     a = ap.parse_args()
+    blocks = 2 if a.config == "c4" else 1
+    if a.clips is None:
+        a.clips = 512 if a.config == "c4" else 256
+    if a.z is None:
+        a.z = 512 if a.config == "c4" else 128
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
@@ -282,7 +291,7 @@ def main():
     M = importlib.import_module(PKG + ".model")
 
     torch.manual_seed(0)                      # identical initial weights on every rank (and broadcast below)
-    model = M.VAE(1, 32, 1, 2, a.z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype=a.dtype).to(device).train()
+    model = M.VAE(1, 32, 1, 2, a.z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype=a.dtype, blocks_per_stage=blocks).to(device).train()
     opt = M.FusedAdam(list(model.parameters()))
     if world > 1:
         M.GradSync(model, sync_bn=a.sync_bn, comm=a.comm)
@@ -320,9 +329,9 @@ def main():
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {a.clips} clips x 20 frames x 64x64 per GPU per step (={frames} frames), "
-                                   f"conv-VAE z={a.z}, Gaussian NLL sigma=0.1 + KL (normal_vae_1_kl_0_mmd), Adam, "
-                                   f"random-init weights, Bernoulli({P_ON}) q=2 labels",
+            "config": {"workload": (f"BASELINE configs[{1 if a.config == 'c2' else 3}]: {a.clips} clips x 20 frames x 64x64 per GPU per step (={frames} frames), "
+                                    f"conv-VAE{'' if blocks == 1 else f' ({blocks} residual blocks per stage: deeper, build-defined)'} z={a.z}, "
+                                    f"Gaussian NLL sigma=0.1 + KL (normal_vae_1_kl_0_mmd), Adam, random-init weights, Bernoulli({P_ON}) q=2 labels"),
                        "global_frames_per_step": world * frames, "parallelism": f"dp{world}", "rccl_ranks": ranks_seen,
                        "grad_exchange": ("none" if world == 1 else ("mmvae_comm_allreduce (library RCCL communicator)" if a.comm == "rccl"
                                                                    else "torch.distributed nccl (= RCCL)")) ,
@@ -334,8 +343,15 @@ def main():
                                   "mfma_frac_of_2.5PF": value / world * TRAIN_FLOP_PER_FRAME / 2.5e15},
             "build": importlib.import_module(PKG + "._lib").build_hash(),
         }
-        out["step_traffic_ratio"] = step_traffic(frames)
-    if world == 1 and not a.no_roofline:
+        if a.config == "c4":
+            # algorithmic work of the deeper variant per frame (conv / convT MACs x 2, forward + both gradients; counted from the layer
+            # table like SURVEY 8d): the MFMA-bound stress configuration is judged against the bf16 MFMA peak
+            fl = C4_TRAIN_FLOP_PER_FRAME[a.z] if a.z in C4_TRAIN_FLOP_PER_FRAME else None
+            out["step_hbm_roofline"] = None
+            out["step_mfma_roofline"] = None if fl is None else {"train_flop_per_frame": fl, "achieved_TFLOPs": value / world * fl / 1e12,
+                                                                 "frac_of_2.5PF": value / world * fl / 2.5e15}
+        out["step_traffic_ratio"] = step_traffic(frames) if a.config == "c2" else None
+    if world == 1 and not a.no_roofline and a.config == "c2":
         # the other reading of "batch 256" (SURVEY 8): 256 FRAMES per step, same model -- a latency-bound point, for reference
         b256 = (torch.rand((256, 64, 64), generator=torch.Generator().manual_seed(99)) < P_ON).long().to(device)
         run(3, b256)
@@ -346,12 +362,12 @@ def main():
         d256 = (time.perf_counter() - t1) / 20
         out["batch256_frames"] = {"frames_per_sec": 256 / d256, "ms_per_step": 1e3 * d256, "note": "256 frames (not clips) per step"}
     if rank == 0:
-        if not a.no_roofline:
+        if not a.no_roofline and a.config == "c2":
             out["roofline"] = dominant_kernel_roofline(M, device, frames)
             if a.dtype == "bf16":
                 out["roofline_largest_launch"] = largest_launch_roofline(M, device, frames)
             out["elbo_rel_err_vs_cpu_oracle"] = elbo_check(M, device, a.dtype)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.config == "c2":
             out["cpu_baseline"] = cpu_baseline(a.z)
         print(json.dumps(out), flush=True)
     if dist is not None:

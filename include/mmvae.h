@@ -51,6 +51,13 @@ MMVAE_API const char* mmvae_last_error(void);          /* host string, valid unt
 typedef struct mmvae_net mmvae_net;
 MMVAE_API int mmvae_net_create(mmvae_net** out, int in_channels, int z_dimension, int out_channels, int image_size,
                      int need_logvar, int dtype);
+/* Deeper-than-reference variant (BASELINE configs[3]): blocks_per_stage residual blocks in every encoder stage (_make_layer with
+ * blocks > 1, model.py:132-146: the extra BasicBlocks keep the shape and have an identity shortcut) and in every decoder stage
+ * (_make_up_block with num_layer > 1, model.py:196-209: the extra blocks come first; the reference's own extra DeconvBottleneck
+ * cannot run -- 2x main path against an identity shortcut, :205-206 -- so here it is conv1x1 -> BN -> ReLU -> conv3x3 -> BN, +
+ * identity, ReLU).  blocks_per_stage = 1 is the reference network. */
+MMVAE_API int mmvae_net_create_ex(mmvae_net** out, int in_channels, int z_dimension, int out_channels, int image_size,
+                        int need_logvar, int dtype, int blocks_per_stage);
 MMVAE_API void mmvae_net_destroy(mmvae_net* net);
 /* Flat storage sizes: f32 parameters, f32 BN running statistics, int64 num_batches_tracked counters; first
  * decoder parameter (for gradient bucketing); decoder output side (32 or 64, model.py:169,191). */

@@ -19,6 +19,7 @@ PROTOTYPES = {
     "mmvae_abi_version": (c_int, []),
     "mmvae_last_error": (c_char_p, []),
     "mmvae_net_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int]),
+    "mmvae_net_create_ex": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "mmvae_net_destroy": (None, [P]),
     "mmvae_net_sizes": (c_int, [P, POINTER(c_int64), POINTER(c_int64), POINTER(c_int32), POINTER(c_int64), POINTER(c_int32)]),
     "mmvae_net_num_entries": (c_int, [P]),

@@ -20,14 +20,19 @@ int mmvae_abi_version(void) { return 1; }
 const char* mmvae_last_error(void) { return last_error(); }
 
 int mmvae_net_create(mmvae_net** out, int in_channels, int z, int out_channels, int image_size, int need_logvar, int dtype) {
+  return mmvae_net_create_ex(out, in_channels, z, out_channels, image_size, need_logvar, dtype, 1);
+}
+int mmvae_net_create_ex(mmvae_net** out, int in_channels, int z, int out_channels, int image_size, int need_logvar, int dtype,
+                        int blocks_per_stage) {
   if (!out) return MMVAE_ERR_ARG;
+  if (blocks_per_stage < 1 || blocks_per_stage > 4) { set_error("blocks_per_stage=%d unsupported (1..4)", blocks_per_stage); return MMVAE_ERR_UNSUPPORTED; }
   if (in_channels != 1) { set_error("in_channels=%d unsupported (the hot path is the 1-channel Moving-MNIST VAE)", in_channels); return MMVAE_ERR_UNSUPPORTED; }
   if (z <= 0 || z % 8) { set_error("z_dimension=%d must be a positive multiple of 8", z); return MMVAE_ERR_UNSUPPORTED; }
   if (!(out_channels == 1 || out_channels == 2 || out_channels == 3 || out_channels == 4 || out_channels == 8)) {
     set_error("decoder_out_channels=%d unsupported (1,2,3,4,8)", out_channels); return MMVAE_ERR_UNSUPPORTED; }
   if (image_size < 9 || image_size > 64) { set_error("input_image_size=%d unsupported (9..64)", image_size); return MMVAE_ERR_UNSUPPORTED; }
   if (dtype != MMVAE_F32 && dtype != MMVAE_BF16) { set_error("dtype=%d unsupported", dtype); return MMVAE_ERR_ARG; }
-  NetCfg c{in_channels, z, out_channels, image_size, need_logvar ? 1 : 0, dtype};
+  NetCfg c{in_channels, z, out_channels, image_size, need_logvar ? 1 : 0, dtype, blocks_per_stage};
   mmvae_net* h = new (std::nothrow) mmvae_net;
   if (!h) return MMVAE_ERR_ARG;
   h->net = new (std::nothrow) Net(c);

@@ -273,6 +273,7 @@ int launch_normalise(int dt, const long long* labels, long n, float mean, float 
 int launch_quantise_normalise(const unsigned char* frames, long n, const float* centres, int q, float mean, float stdv,
                               long long* labels, float* image, hipStream_t s);
 int launch_convert(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s);
+int launch_fill_f32(float* p, float v, long n, hipStream_t s);
 int launch_concat2_to_t(int dt, const float* a, const float* b, int rows, int ca, int cb, void* out, hipStream_t s);
 int launch_loss_finish(const double* acc, float* out, float nll, float klc, float mmdc, float n, hipStream_t s);
 // out[c] += sum_p partials[p*row_stride + c]  (c < C)

@@ -532,6 +532,16 @@ int launch_convert(int dt_in, int dt_out, const void* in, void* out, long n, hip
 }
 
 // out[r][0..ca) = a[r][:], out[r][ca..ca+cb) = b[r][:]   (f32 -> T); b may be null (cb = 0)
+__global__ void fill_f32_kernel(float* p, float v, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+int launch_fill_f32(float* p, float v, long n, hipStream_t s) {
+  if (n <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+  return check_launch("fill_f32");
+}
+
 template <typename T>
 __global__ void concat2_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows, int ca, int cb, T* __restrict__ out) {
   const long total = (long)rows * (ca + cb);

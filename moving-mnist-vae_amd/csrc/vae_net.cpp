@@ -55,17 +55,26 @@ Net::Net(const NetCfg& c) : cfg(c) {
   bn0 = add_bn("encoder.bn1", 32);
   int inpl = 32, H = H1;
   const int planes[4] = {32, 64, 128, 256};
+  const int nb = c.blocks < 1 ? 1 : c.blocks;
   for (int i = 0; i < 4; ++i) {
-    Block& B = enc[i];
-    const std::string p = "encoder.layer" + std::to_string(i + 1) + ".0.";
-    B.Cin = inpl; B.C = planes[i]; B.Hin = B.Win = H; B.Hout = B.Wout = down_size(H, 3, 2, 1); B.Hmid = B.Wmid = B.Hout;
-    B.c1 = add_conv(p + "conv1.weight", planes[i], inpl, 3, 2, 1, true);       // conv3x3 stride 2 (:29,:98-101)
-    B.b1 = add_bn(p + "bn1", planes[i]);
-    B.c2 = add_conv(p + "conv2.weight", planes[i], planes[i], 3, 1, 1, true);  // conv3x3 (:33)
-    B.b2 = add_bn(p + "bn2", planes[i]);
-    B.cs = add_conv(p + "downsample.0.weight", planes[i], inpl, 1, 2, 0, true);  // conv1x1 stride 2 (:135-138)
-    B.bs = add_bn(p + "downsample.1", planes[i]);
-    inpl = planes[i]; H = B.Hout;
+    for (int b = 0; b < nb; ++b) {
+      // _make_layer (model.py:132-146): block 0 strides and carries the 1x1 downsample shortcut, the others keep the shape
+      Block B;
+      const std::string p = "encoder.layer" + std::to_string(i + 1) + "." + std::to_string(b) + ".";
+      const int st = b == 0 ? 2 : 1;
+      B.identity = b > 0;
+      B.Cin = inpl; B.C = planes[i]; B.Hin = B.Win = H; B.Hout = B.Wout = down_size(H, 3, st, 1); B.Hmid = B.Wmid = B.Hout;
+      B.c1 = add_conv(p + "conv1.weight", planes[i], inpl, 3, st, 1, true);       // conv3x3 (:29,:98-101)
+      B.b1 = add_bn(p + "bn1", planes[i]);
+      B.c2 = add_conv(p + "conv2.weight", planes[i], planes[i], 3, 1, 1, true);  // conv3x3 (:33)
+      B.b2 = add_bn(p + "bn2", planes[i]);
+      if (!B.identity) {
+        B.cs = add_conv(p + "downsample.0.weight", planes[i], inpl, 1, 2, 0, true);  // conv1x1 stride 2 (:135-138)
+        B.bs = add_bn(p + "downsample.1", planes[i]);
+      }
+      inpl = planes[i]; H = B.Hout;
+      enc.push_back(B);
+    }
   }
   Hf = Wf = H;
   head_mu = add_conv("encoder.conv_mu.weight", c.z, 256, 1, 1, 0, false);
@@ -85,16 +94,31 @@ Net::Net(const NetCfg& c) : cfg(c) {
   const int ups[5] = {128, 64, 32, 16, 16};
   int cin = 128; H = 2;
   for (int i = 0; i < nup; ++i) {
-    Block& B = dec[i];
-    const std::string p = "decoder.uplayer" + std::to_string(i + 1) + ".0.";
-    B.Cin = cin; B.C = ups[i]; B.Hin = B.Win = H; B.Hmid = B.Wmid = H; B.Hout = B.Wout = 2 * H;
-    B.c1 = add_conv(p + "conv1.weight", ups[i], cin, 1, 1, 0, true);        // 1x1 (:60)
-    B.b1 = add_bn(p + "bn1", ups[i]);
-    B.c2 = add_conv(p + "conv2.weight", ups[i], ups[i], 4, 2, 1, true);      // ConvT k4 s2 p1 (:62-65)
-    B.b2 = add_bn(p + "bn2", ups[i]);
-    B.cs = add_conv(p + "upsample.0.weight", cin, ups[i], 4, 2, 1, true);    // ConvT k4 s2 p1 (:198-201)
-    B.bs = add_bn(p + "upsample.1", ups[i]);
-    cin = ups[i]; H = 2 * H;
+    for (int b = 0; b < nb; ++b) {
+      // _make_up_block (model.py:196-209): the extra blocks come FIRST and the upsampling block last.  The reference builds the extra
+      // ones as block(in, out) with the 2x ConvTranspose2d main path and an identity shortcut, which cannot run (shape mismatch,
+      // :205-206); here they keep the stage's input shape: conv1x1 -> BN -> ReLU -> conv3x3 -> BN, + identity, ReLU.
+      Block B;
+      const std::string p = "decoder.uplayer" + std::to_string(i + 1) + "." + std::to_string(b) + ".";
+      B.identity = b < nb - 1;
+      if (B.identity) {
+        B.Cin = cin; B.C = cin; B.Hin = B.Win = H; B.Hmid = B.Wmid = H; B.Hout = B.Wout = H;
+        B.c1 = add_conv(p + "conv1.weight", cin, cin, 1, 1, 0, true);
+        B.b1 = add_bn(p + "bn1", cin);
+        B.c2 = add_conv(p + "conv2.weight", cin, cin, 3, 1, 1, true);           // Conv2d (out,in,3,3): the shape-preserving main path
+        B.b2 = add_bn(p + "bn2", cin);
+      } else {
+        B.Cin = cin; B.C = ups[i]; B.Hin = B.Win = H; B.Hmid = B.Wmid = H; B.Hout = B.Wout = 2 * H;
+        B.c1 = add_conv(p + "conv1.weight", ups[i], cin, 1, 1, 0, true);        // 1x1 (:60)
+        B.b1 = add_bn(p + "bn1", ups[i]);
+        B.c2 = add_conv(p + "conv2.weight", ups[i], ups[i], 4, 2, 1, true);      // ConvT k4 s2 p1 (:62-65)
+        B.b2 = add_bn(p + "bn2", ups[i]);
+        B.cs = add_conv(p + "upsample.0.weight", cin, ups[i], 4, 2, 1, true);    // ConvT k4 s2 p1 (:198-201)
+        B.bs = add_bn(p + "upsample.1", ups[i]);
+        cin = ups[i]; H = 2 * H;
+      }
+      dec.push_back(B);
+    }
   }
   Sd = H;
   tail = add_conv("decoder.conv2.weight", c.out_ch, 16, 3, 1, 1, false);
@@ -114,18 +138,18 @@ const Plan& Net::plan(int N) {
   auto act = [&](long elems) { maxact = std::max(maxact, elems * e); return take(elems * e); };
   P.x_t = act((long)N * cfg.S * cfg.S);
   P.y0 = act((long)N * H1 * W1 * 32);
-  for (int i = 0; i < 4; ++i) {
-    Block& B = enc[i];
+  for (Block& B : enc) {
     const long n = (long)N * B.Hout * B.Wout * B.C;
-    B.y1 = act(n); B.y2 = act(n); B.ys = act(n); B.out = act(n);
+    B.y1 = act(n); B.y2 = act(n); B.ys = B.identity ? 0 : act(n); B.out = act(n);
   }
   P.enc_t = act((long)N * cfg.z);
   P.y0d = act((long)N * 4 * 128);
-  for (int i = 0; i < nup; ++i) {
-    Block& B = dec[i];
+  P.act0d = cfg.blocks > 1 ? act((long)N * 4 * 128) : 0;
+  for (Block& B : dec) {
     const long n = (long)N * B.Hout * B.Wout * B.C;
-    B.y1 = act((long)N * B.Hin * B.Win * B.C); B.y2 = act(n); B.ys = act(n); B.out = act(n);
+    B.y1 = act((long)N * B.Hin * B.Win * B.C); B.y2 = act(n); B.ys = B.identity ? 0 : act(n); B.out = act(n);
   }
+  P.cvec = take(512 * 4);
   P.r_raw = take((long)N * cfg.out_ch * Sd * Sd * 4);
   P.d_raw = take((long)N * cfg.out_ch * Sd * Sd * 4);
   P.col = act((long)N * H1 * W1 * 32);
@@ -135,8 +159,9 @@ const Plan& Net::plan(int N) {
   P.syncbuf = take(2 * 1024 * 4);
   for (int i = 0; i < 2; ++i) P.g[i] = take(maxact);
   for (int i = 0; i < 2; ++i) { P.dy1[i] = take(maxact); P.dy2[i] = take(maxact); P.dys[i] = take(maxact); }
-  for (int i = 0; i < 2; ++i) {
-    const long nb = (long)N * enc[i + 2].Hout * enc[i + 2].Wout * enc[i + 2].C * e;
+  for (int i = 0; i < 2; ++i) {        // private dy sets of the two encoder blocks the backward pass visits first
+    const Block& B = enc[enc.size() - 2 + i];
+    const long nb = (long)N * B.Hout * B.Wout * B.C * e;
     P.edy1[i] = take(nb); P.edy2[i] = take(nb); P.edys[i] = take(nb);
   }
   P.da1 = take(maxact);
@@ -147,6 +172,12 @@ const Plan& Net::plan(int N) {
   P.bytes = (size_t)cur;
   plan_ = P;
   return plan_;
+}
+
+int Net::fill_consts(char* base, hipStream_t s) {
+  float* c = reinterpret_cast<float*>(base + plan_.cvec);
+  MM_TRY(launch_fill_f32(c, 1.f, 256, s));
+  return launch_fill_f32(c + 256, 0.f, 256, s);
 }
 
 float* Net::bnf(const Bn& bn, char* base, int which) const {
@@ -185,7 +216,7 @@ hipStream_t Net::wgrad_stream(hipStream_t s) {
     if (side_state_ == 1) {
       bool ok = hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) == hipSuccess;
       for (int i = 0; i < 64 && ok; ++i) ok = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
-      for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreateWithFlags(&blk_ev_[i], hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&blk_ev_[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); side_state_ = -1; }
     }
   }
@@ -218,12 +249,12 @@ static bool stem_im2col_path() {
 
 int Net::side_mark(int slot) {
   if (side_state_ != 1) return MMVAE_OK;
-  if (hipEventRecord(blk_ev_[slot & 7], side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
+  if (hipEventRecord(blk_ev_[slot & 15], side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
   return MMVAE_OK;
 }
 int Net::side_wait_mark(int slot, hipStream_t s) {
   if (side_state_ != 1) return MMVAE_OK;
-  if (hipStreamWaitEvent(s, blk_ev_[slot & 7], 0) != hipSuccess) { set_error("side stream wait failed"); return MMVAE_ERR_HIP; }
+  if (hipStreamWaitEvent(s, blk_ev_[slot & 15], 0) != hipSuccess) { set_error("side stream wait failed"); return MMVAE_ERR_HIP; }
   return MMVAE_OK;
 }
 
@@ -236,7 +267,7 @@ bool Net::tail_fwd_fused() const {
   static const bool env = [] { const char* e = getenv("MMVAE_TAIL_FWD_FUSED"); return !(e && e[0] == '0'); }();
   static const bool bwd_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
   // N does not enter the geometry checks beyond the tile count limit, which the plan's maximum batch already satisfies
-  return env && bwd_env && nup >= 1 && dec[nup - 1].C == 16 && tail_fwd_fusable(dt(), cfg.out_ch, 1, Sd, Sd) &&
+  return env && bwd_env && !dec.empty() && dec.back().C == 16 && tail_fwd_fusable(dt(), cfg.out_ch, 1, Sd, Sd) &&
          tail_join_fusable(dt(), cfg.out_ch, 1, Sd, Sd);
 }
 
@@ -325,10 +356,10 @@ int Net::packs_enc_fwd(const float* params, char* base, hipStream_t s) {
     for (int t = 0; t < 25; ++t) pa.tap_off[t] = t;
     MM_TRY(launch_pack(dt(), pa, s));
   }
-  for (int i = 0; i < 4; ++i) {
-    MM_TRY(pack_down(enc[i].c1, params, base, s));
-    MM_TRY(pack_down(enc[i].c2, params, base, s));
-    MM_TRY(pack_down(enc[i].cs, params, base, s));
+  for (const Block& B : enc) {
+    MM_TRY(pack_down(B.c1, params, base, s));
+    MM_TRY(pack_down(B.c2, params, base, s));
+    if (!B.identity) MM_TRY(pack_down(B.cs, params, base, s));
   }
   const int nt = Hf * Wf;
   for (int h = 0; h < (cfg.need_logvar ? 2 : 1); ++h) {
@@ -349,10 +380,10 @@ int Net::packs_enc_bwd(const float* params, char* base, hipStream_t s) {
   pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
   pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / (Hf * Wf);
   MM_TRY(launch_pack(dt(), pa, s));
-  for (int i = 0; i < 4; ++i) {
-    MM_TRY(pack_up(enc[i].c2, params, base, s));
-    MM_TRY(pack_up(enc[i].c1, params, base, s));
-    MM_TRY(pack_up(enc[i].cs, params, base, s));
+  for (const Block& B : enc) {
+    MM_TRY(pack_up(B.c2, params, base, s));
+    MM_TRY(pack_up(B.c1, params, base, s));
+    if (!B.identity) MM_TRY(pack_up(B.cs, params, base, s));
   }
   return MMVAE_OK;
 }
@@ -360,10 +391,10 @@ int Net::packs_enc_bwd(const float* params, char* base, hipStream_t s) {
 int Net::packs_dec_fwd(const float* params, char* base, hipStream_t s) {
   const Plan& P = plan_;
   MM_TRY(pack_up(dstem, params, base, s));
-  for (int i = 0; i < nup; ++i) {
-    MM_TRY(pack_down(dec[i].c1, params, base, s));
-    MM_TRY(pack_up(dec[i].c2, params, base, s));
-    MM_TRY(pack_up(dec[i].cs, params, base, s));
+  for (const Block& B : dec) {
+    MM_TRY(pack_down(B.c1, params, base, s));
+    if (B.identity) MM_TRY(pack_down(B.c2, params, base, s));       // 3x3 Conv2d
+    else { MM_TRY(pack_up(B.c2, params, base, s)); MM_TRY(pack_up(B.cs, params, base, s)); }
   }
   PackArgs pa; std::memset(&pa, 0, sizeof(pa));
   pa.src = params + tail.off; pa.dst = base + P.packed + tail_pack_f * (long)esz();
@@ -380,10 +411,10 @@ int Net::packs_dec_bwd(const float* params, char* base, bool need_denc, hipStrea
   pa.cols = 16; pa.K = 8; pa.K_valid = cfg.out_ch; pa.ntaps = 9; pa.s_col = 9; pa.s_k = 144; pa.scale = 1.f;
   for (int t = 0; t < 9; ++t) pa.tap_off[t] = t;
   MM_TRY(launch_pack(dt(), pa, s));
-  for (int i = 0; i < nup; ++i) {
-    MM_TRY(pack_down(dec[i].c2, params, base, s));
-    MM_TRY(pack_up(dec[i].c1, params, base, s));
-    MM_TRY(pack_down(dec[i].cs, params, base, s));
+  for (const Block& B : dec) {
+    MM_TRY(pack_up(B.c1, params, base, s));
+    if (B.identity) MM_TRY(pack_up(B.c2, params, base, s));
+    else { MM_TRY(pack_down(B.c2, params, base, s)); MM_TRY(pack_down(B.cs, params, base, s)); }
   }
   if (need_denc) MM_TRY(pack_down(dstem, params, base, s));
   return MMVAE_OK;
@@ -437,16 +468,21 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   const void* xin = base + P.y0;
   const float* xs = bnf(bn0, base, 2);
   const float* xb = bnf(bn0, base, 3);
-  for (int i = 0; i < 4; ++i) {
+  if (cfg.blocks > 1) MM_TRY(fill_consts(base, s));
+  for (size_t i = 0; i < enc.size(); ++i) {
     Block& B = enc[i];
     const double cnt = (double)N * B.Hout * B.Wout;
     // shortcut branch (conv + its BatchNorm) on the side stream, concurrently with conv1 -> bn1 -> conv2 -> bn2
     static const bool side_fwd = [] { const char* e = getenv("MMVAE_SIDE_FWD"); return !(e && e[0] == '0'); }();
-    if (side_fwd) MM_TRY(side_fork(s));
-    hipStream_t ss = side_fwd ? wgrad_stream(s) : s;
-    int np = run_down(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, dt(), ss);
-    MM_TRY(np);
-    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
+    const bool fork = side_fwd && !B.identity;
+    int np;
+    if (!B.identity) {
+      if (fork) MM_TRY(side_fork(s));
+      hipStream_t ss = fork ? wgrad_stream(s) : s;
+      np = run_down(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, dt(), ss);
+      MM_TRY(np);
+      MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
+    }
     np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b1, params, bnbuf, base, s));
@@ -454,9 +490,11 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
                   stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
-    if (side_fwd) MM_TRY(side_join(s));
-    MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2),
-                           bnf(B.bs, base, 3), base + B.out, (long)N * B.Hout * B.Wout, B.C, s));
+    if (fork) MM_TRY(side_join(s));
+    // identity shortcut (model.py:40,52): the block input itself, i.e. a unit "BatchNorm" (scale 1, shift 0) of it
+    MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), B.identity ? xin : base + B.ys,
+                           B.identity ? ones(base) : bnf(B.bs, base, 2), B.identity ? zeros(base) : bnf(B.bs, base, 3), base + B.out,
+                           (long)N * B.Hout * B.Wout, B.C, s));
     xin = base + B.out; xs = xb = nullptr;
   }
   // global average pool + the two 1x1 heads (model.py:123-128) as ONE k=Hf,s=Hf conv whose taps share W/(Hf*Wf)
@@ -493,7 +531,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
   MM_TRY(launch_concat2_to_t(dt(), d_mu, cfg.need_logvar ? d_logvar : nullptr, N, cfg.z, cfg.need_logvar ? cfg.z : 0, base + P.dh, s));
   {
     WgradArgs a; std::memset(&a, 0, sizeof(a));
-    a.P = base + P.dh; a.G = base + enc[3].out; a.dW = grads + head_mu.off; a.proP_relu = a.proG_relu = 0;
+    a.P = base + P.dh; a.G = base + enc.back().out; a.dW = grads + head_mu.off; a.proP_relu = a.proG_relu = 0;
     a.N = N; a.Hp = 1; a.Wp = 1; a.Ca = Ch; a.Hg = Hf; a.Wg = Wf; a.Cb = 256; a.Cb_valid = 256;
     a.stride = Hf; a.pad = 0; a.ksz = Hf; a.sA = 256; a.sB = 1; a.ntaps = nt; a.scale = 1.0f / nt;
     a.scratch = wscratch_;
@@ -516,7 +554,8 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(launch_gather_gemm(dt(), dt(), g, s));
   }
   int cur = 0;   // d_out lives in g[cur]
-  for (int i = 3; i >= 0; --i) {
+  const int ne = (int)enc.size();
+  for (int i = ne - 1; i >= 0; --i) {
     Block& B = enc[i];
     const long npix = (long)N * B.Hout * B.Wout;
     const double cnt = (double)npix;
@@ -525,26 +564,33 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     const float* xb = i == 0 ? bnf(bn0, base, 3) : nullptr;
     // dy1 / dy2 / dys alternate between two sets, so this block only has to wait for the weight gradients of the block
     // before the previous one (the side stream may lag one block behind)
-    // Blocks 3 and 2 (small tensors) own private sets: with a deferred decoder join the side stream may still be reading the
-    // shared sets for the decoder's weight gradients when they start.  Block 1 waits for block 3's mark, which -- the side
-    // stream being in order -- also covers everything the decoder left there.
+    // The two blocks visited first (small tensors) own private sets: with a deferred decoder join the side stream may still be
+    // reading the shared sets for the decoder's weight gradients when they start.  The third block waits for the first one's
+    // mark, which -- the side stream being in order -- also covers everything the decoder left there.
     const int ds = i & 1;
-    const long dy1o = i >= 2 ? P.edy1[i - 2] : P.dy1[ds], dy2o = i >= 2 ? P.edy2[i - 2] : P.dy2[ds], dyso = i >= 2 ? P.edys[i - 2] : P.dys[ds];
-    if (i + 2 <= 3) MM_TRY(side_wait_mark(i + 2, s));
+    const bool priv = i >= ne - 2;
+    const long dy1o = priv ? P.edy1[i - (ne - 2)] : P.dy1[ds], dy2o = priv ? P.edy2[i - (ne - 2)] : P.dy2[ds];
+    // an identity shortcut's gradient is the masked incoming gradient itself: it goes straight into the block-input gradient
+    const long dyso = B.identity ? P.g[cur ^ 1] : (priv ? P.edys[i - (ne - 2)] : P.dys[ds]);
+    if (i + 2 <= ne - 1) MM_TRY(side_wait_mark(i + 2, s));
+    const void* ysp = B.identity ? xin : base + B.ys;
+    const float* ssc = B.identity ? ones(base) : bnf(B.bs, base, 2);
+    const float* ssh = B.identity ? zeros(base) : bnf(B.bs, base, 3);
     // join backward: g = d_out * [out > 0] feeds bn2 (y2) and the shortcut BN (ys)
-    int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npix, B.C, part, s,
-                                  bnf(B.bs, base, 2), bnf(B.bs, base, 3));
+    int np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, ysp, npix, B.C, part, s, ssc, ssh);
     MM_TRY(np);
-    MM_TRY(bn_backward_coefs_join(B.b2, B.bs, params, grads, base, np, cnt, s));
+    if (B.identity) MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, cnt, s));
+    else MM_TRY(bn_backward_coefs_join(B.b2, B.bs, params, grads, base, np, cnt, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
-                               bnf(B.b2, base, 6), base + dy2o, base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                               base + dyso, npix, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
+                               bnf(B.b2, base, 6), base + dy2o, ysp, B.identity ? ones(base) : bnf(B.bs, base, 4),
+                               B.identity ? zeros(base) : bnf(B.bs, base, 5), B.identity ? zeros(base) : bnf(B.bs, base, 6), base + dyso, npix, B.C, s,
+                               ssc, ssh));
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
     MM_TRY(run_wgrad(B.c2, N, base + dy2o, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
                      bnf(B.b1, base, 3), grads, wsm));
-    MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    if (!B.identity) MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(run_up(B.c2, base, N, base + dy2o, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
     // bn1 + relu backward
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
@@ -553,13 +599,15 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),
                                bnf(B.b1, base, 5), bnf(B.b1, base, 6), base + dy1o, nullptr, nullptr, nullptr, nullptr, nullptr, npix,
                                B.C, s));
-    // conv1 (3x3 s2) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
+    // conv1 (3x3) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
     MM_TRY(side_fork(s));
     MM_TRY(run_wgrad(B.c1, N, base + dy1o, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(side_mark(i));
-    // one kernel: the 1x1 stride-2 shortcut's data gradient is a second source of the 3x3 conv's (phase (0,0)); no read-modify-write
-    MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s, &B.cs,
-                  base + dyso));
+    if (B.identity)     // d_xin already holds the shortcut's share: the main path's data gradient is added to it
+      MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
+    else                // one kernel: the 1x1 stride-2 shortcut's data gradient is a second source of the 3x3 conv's (phase (0,0))
+      MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s, &B.cs,
+                    base + dyso));
     cur ^= 1;
   }
   // ---- stem: bn0 + relu backward and the 5x5 weight gradient
@@ -634,33 +682,47 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   const void* xin = base + P.y0d;
   const float* xs = bnf(dbn0, base, 2);
   const float* xb = bnf(dbn0, base, 3);
-  for (int i = 0; i < nup; ++i) {
+  const int nd = (int)dec.size();
+  if (cfg.blocks > 1) {
+    // the first block of a deeper decoder has an identity shortcut: it needs the stem's activation as a tensor
+    MM_TRY(fill_consts(base, s));
+    MM_TRY(launch_affine_act(dt(), base + P.y0d, xs, xb, 1, base + P.act0d, (long)N * 4, 128, s));
+    xin = base + P.act0d; xs = xb = nullptr;
+  }
+  for (int i = 0; i < nd; ++i) {
     Block& B = dec[i];
     const double cnt = (double)N * B.Hout * B.Wout;
     // upsample (shortcut) branch on the side stream, concurrently with conv1 -> bn1 -> conv2 -> bn2
     static const bool side_fwd = [] { const char* e = getenv("MMVAE_SIDE_FWD"); return !(e && e[0] == '0'); }();
-    if (side_fwd) MM_TRY(side_fork(s));
-    hipStream_t ss = side_fwd ? wgrad_stream(s) : s;
-    np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, ss);
-    MM_TRY(np);
-    MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
+    const bool fork = side_fwd && !B.identity;
+    if (!B.identity) {
+      if (fork) MM_TRY(side_fork(s));
+      hipStream_t ss = fork ? wgrad_stream(s) : s;
+      np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, ss);
+      MM_TRY(np);
+      MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
+    }
     np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hin, B.Win, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, (double)N * B.Hin * B.Win, s) : bn_eval(B.b1, params, bnbuf, base, s));
-    np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
+    if (B.identity)    // 3x3 Conv2d, shape preserving
+      np = run_down(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, dt(), s);
+    else
+      np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
-    if (side_fwd) MM_TRY(side_join(s));
-    if (i == nup - 1 && tail_fwd_fused()) break;     // the join of the last block happens inside the tail conv kernel
-    MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2),
-                           bnf(B.bs, base, 3), base + B.out, (long)N * B.Hout * B.Wout, B.C, s));
+    if (fork) MM_TRY(side_join(s));
+    if (i == nd - 1 && tail_fwd_fused()) break;     // the join of the last block happens inside the tail conv kernel
+    MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), B.identity ? xin : base + B.ys,
+                           B.identity ? ones(base) : bnf(B.bs, base, 2), B.identity ? zeros(base) : bnf(B.bs, base, 3), base + B.out,
+                           (long)N * B.Hout * B.Wout, B.C, s));
     xin = base + B.out; xs = xb = nullptr;
   }
   // tail conv (+bias) and the output BatchNorm (model.py:193)
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
   static const bool tail_direct_f = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
   if (tail_fwd_fused()) {
-    const Block& B = dec[nup - 1];
+    const Block& B = dec.back();
     np = launch_tail_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
                               params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
     MM_TRY(np);
@@ -720,26 +782,26 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   static const bool tail_wgrad_tile_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_TILE"); return !(e && e[0] == '0'); }();
   static const bool tail_fused_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
   static const bool tail_wg_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_IN_REDUCE"); return !(e && e[0] == '0'); }();
-  const bool tail_fused = tail_fused_env && nup >= 1 && dec[nup - 1].C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
+  const bool tail_fused = tail_fused_env && !dec.empty() && dec.back().C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
   // forward did not store the joined activation: the weight gradient recomputes it, inside the join-backward reduce pass (below)
   // or, MMVAE_TAIL_WGRAD_IN_REDUCE=0, in its own kernel on the side stream
   const bool tail_wg_in_reduce = tail_fwd_fused() && tail_fused && tail_wg_env;
   if (tail_wg_in_reduce) {
   } else if (tail_fwd_fused()) {
-    const Block& B = dec[nup - 1];
+    const Block& B = dec.back();
     MM_TRY(side_fork(s));
     MM_TRY(launch_tail_wgrad_tile(dt(), base + B.y2, base + B.ys, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2), bnf(B.bs, base, 3),
                                   d_raw, grads + tail.off, wscratch_, N, Sd, Sd, wgrad_stream(s)));
   } else if (tail_wgrad_direct) {
-    MM_TRY(launch_tail_wgrad(dt(), base + dec[nup - 1].out, d_raw, grads + tail.off, nullptr, N, Sd, Sd, cfg.out_ch, s));
-  } else if (tail_wgrad_tile_env && cfg.out_ch == 1 && nup >= 1 && tail_join_fusable(dt(), 1, N, Sd, Sd)) {
+    MM_TRY(launch_tail_wgrad(dt(), base + dec.back().out, d_raw, grads + tail.off, nullptr, N, Sd, Sd, cfg.out_ch, s));
+  } else if (tail_wgrad_tile_env && cfg.out_ch == 1 && !dec.empty() && tail_join_fusable(dt(), 1, N, Sd, Sd)) {
     MM_TRY(side_fork(s));
-    MM_TRY(launch_tail_wgrad_tile(dt(), base + dec[nup - 1].out, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, grads + tail.off, wscratch_,
+    MM_TRY(launch_tail_wgrad_tile(dt(), base + dec.back().out, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, grads + tail.off, wscratch_,
                                   N, Sd, Sd, wgrad_stream(s)));
   } else {
     // dW[oc][ci][kh][kw]: P = d_raw (planar f32, out_ch planes staged as 16 zero-padded channels), G = the last up-block's output
     WgradArgs a; std::memset(&a, 0, sizeof(a));
-    a.P = d_raw; a.P_planar = 1; a.P_planes = cfg.out_ch; a.G = base + dec[nup - 1].out; a.dW = grads + tail.off; a.scratch = wscratch_;
+    a.P = d_raw; a.P_planar = 1; a.P_planes = cfg.out_ch; a.G = base + dec.back().out; a.dW = grads + tail.off; a.scratch = wscratch_;
     a.N = N; a.Hp = Sd; a.Wp = Sd; a.Ca = 16; a.Ca_valid = cfg.out_ch; a.Hg = Sd; a.Wg = Sd; a.Cb = 16; a.Cb_valid = 16;
     a.stride = 1; a.pad = 1; a.ksz = 3; a.sA = 16 * 9; a.sB = 9; a.ntaps = 9; a.scale = 1.f;
     for (int t = 0; t < 9; ++t) a.tap_off[t] = t;
@@ -766,15 +828,22 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) a.taps[kh * 3 + kw] = Tap{1 - kh, 1 - kw};
     MM_TRY(launch_gather_gemm(dt(), dt(), a, s));
   }
-  for (int i = nup - 1; i >= 0; --i) {
+  const int nd = (int)dec.size();
+  for (int i = nd - 1; i >= 0; --i) {
     Block& B = dec[i];
     const long npo = (long)N * B.Hout * B.Wout, npi = (long)N * B.Hin * B.Win;
-    const void* xin = i == 0 ? base + P.y0d : base + dec[i - 1].out;
-    const float* xs = i == 0 ? bnf(dbn0, base, 2) : nullptr;
-    const float* xb = i == 0 ? bnf(dbn0, base, 3) : nullptr;
+    // (blocks > 1: block 0 has an identity shortcut and reads the stem's materialised activation)
+    const void* xin = i == 0 ? (cfg.blocks > 1 ? base + P.act0d : base + P.y0d) : base + dec[i - 1].out;
+    const float* xs = (i == 0 && cfg.blocks <= 1) ? bnf(dbn0, base, 2) : nullptr;
+    const float* xb = (i == 0 && cfg.blocks <= 1) ? bnf(dbn0, base, 3) : nullptr;
     const int ds = i & 1;          // dy set of this block (see encoder_bwd)
-    if (i + 2 <= nup - 1) MM_TRY(side_wait_mark(i + 2, s));
-    const bool from_tail = tail_fused && i == nup - 1;
+    if (i + 2 <= nd - 1) MM_TRY(side_wait_mark(i + 2, s));
+    const bool from_tail = tail_fused && i == nd - 1;
+    const void* ysp = B.identity ? xin : base + B.ys;
+    const float* ssc = B.identity ? ones(base) : bnf(B.bs, base, 2);
+    const float* ssh = B.identity ? zeros(base) : bnf(B.bs, base, 3);
+    // an identity shortcut's gradient is the masked incoming gradient itself: it goes straight into the block-input gradient
+    const long dyso = B.identity ? P.g[cur ^ 1] : P.dys[ds];
     if (from_tail) {
       np = launch_tail_join_bwd_reduce(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
                                        bnf(B.bs, base, 3), base + B.y2, base + B.ys, part, s, tail_wg_in_reduce ? wscratch_ : nullptr);
@@ -783,25 +852,33 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
         MM_TRY(launch_tail_wgrad_finalize(wscratch_, np, grads + tail.off, wgrad_stream(s)));
       }
     } else
-      np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, base + B.ys, npo, B.C, part, s,
-                                bnf(B.bs, base, 2), bnf(B.bs, base, 3));
+      np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, ysp, npo, B.C, part, s, ssc, ssh);
     MM_TRY(np);
-    MM_TRY(bn_backward_coefs_join(B.b2, B.bs, params, grads, base, np, (double)npo, s));
+    if (B.identity) MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
+    else MM_TRY(bn_backward_coefs_join(B.b2, B.bs, params, grads, base, np, (double)npo, s));
     if (from_tail)
       MM_TRY(launch_tail_join_bwd_apply(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
                                         bnf(B.bs, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5), bnf(B.b2, base, 6), base + P.dy2[ds],
                                         base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6), base + P.dys[ds], s));
     else
       MM_TRY(launch_bn_bwd_apply(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5),
-                                 bnf(B.b2, base, 6), base + P.dy2[ds], base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6),
-                                 base + P.dys[ds], npo, B.C, s, bnf(B.bs, base, 2), bnf(B.bs, base, 3)));
-    // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
+                                 bnf(B.b2, base, 6), base + P.dy2[ds], ysp, B.identity ? ones(base) : bnf(B.bs, base, 4),
+                                 B.identity ? zeros(base) : bnf(B.bs, base, 5), B.identity ? zeros(base) : bnf(B.bs, base, 6), base + dyso, npo, B.C, s,
+                                 ssc, ssh));
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2[ds], B.Hout, B.Wout, nullptr,
-                     nullptr, grads, wsm));
-    MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
-    MM_TRY(run_down(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
+    if (B.identity) {
+      // conv2 (3x3 Conv2d): wgrad(P = dy2, G = a1 with BN+ReLU prologue); dgrad -> d_a1
+      MM_TRY(run_wgrad(B.c2, N, base + P.dy2[ds], B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3),
+                       grads, wsm));
+      MM_TRY(run_up(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
+    } else {
+      // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
+      MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2[ds], B.Hout, B.Wout, nullptr,
+                       nullptr, grads, wsm));
+      MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
+      MM_TRY(run_down(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
+    }
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, (double)npi, s));
@@ -812,14 +889,15 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(side_fork(s));
     MM_TRY(run_wgrad(B.c1, N, base + P.dy1[ds], B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(side_mark(i));
-    // d_xin = dgrad(conv1)(dy1) + dgrad(upsample)(dys)
-    // one kernel: the 1x1 conv's data gradient (dy1, already on this block's input grid) is a second source of the shortcut's
-    MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s,
-                    &B.c1, base + P.dy1[ds]));
+    if (B.identity)     // d_xin already holds the shortcut's share: the 1x1 conv's data gradient is added to it
+      MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
+    else                // one kernel: the 1x1 conv's data gradient (dy1, already on this block's input grid) is a second source of the shortcut's
+      MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s,
+                      &B.c1, base + P.dy1[ds]));
     cur ^= 1;
   }
   // ---- decoder stem
-  if (nup >= 2) MM_TRY(side_wait_mark(1, s));   // the stem uses dy set 1 (block index -1)
+  if (dec.size() >= 2) MM_TRY(side_wait_mark(1, s));   // the stem uses dy set 1 (block index -1)
   const int ds = 1;
   {
     const long npix = (long)N * 4;

@@ -12,7 +12,7 @@
 
 namespace mmvae {
 
-struct NetCfg { int in_ch, z, out_ch, S, need_logvar, dtype; };
+struct NetCfg { int in_ch, z, out_ch, S, need_logvar, dtype, blocks; };   // blocks: residual blocks per stage (reference: 1)
 
 enum EntryKind : int { EK_PARAM = 0, EK_BN_F32 = 1, EK_BN_I64 = 2 };
 struct Entry { std::string name; int ndim; int shape[4]; int kind; long offset; };
@@ -27,6 +27,9 @@ struct Block {   // encoder BasicBlock or decoder DeconvBottleneck (both: main c
   ConvW c1, c2, cs; Bn b1, b2, bs;
   int Cin, C, Hin, Win, Hmid, Wmid, Hout, Wout;
   long y1, y2, ys, out;   // byte offsets in the workspace
+  // identity: a shape-preserving block of a deeper-than-reference net (blocks > 1): no shortcut conv / BatchNorm, the shortcut is
+  // the block input itself (model.py:39-55 with downsample=None; decoder: conv2 is a 3x3 Conv2d instead of the ConvTranspose2d)
+  bool identity = false;
 };
 
 struct Plan {
@@ -42,7 +45,9 @@ struct Plan {
   long g[2], dy1[2], dy2[2], dys[2], da1, dh;            // backward temporaries (dy*: two sets, alternating per block, so the
                                                          // weight gradients on the side stream may lag one block behind)
   long wscratch;                                         // [tap][a][b] reduction image of the largest weight gradient
-  long stem_R, stem_gram;                                // stem backward: patch gram matrix (1024 doubles) and its per-block partials
+  long stem_R, stem_gram;
+  long cvec;                                             // constants: 256 ones, 256 zeros (identity shortcuts as a unit BatchNorm)
+  long act0d;                                            // blocks > 1: relu(bn(decoder stem)) materialised (an identity shortcut needs it)                                // stem backward: patch gram matrix (1024 doubles) and its per-block partials
   long enc_ws_end;
 };
 
@@ -61,10 +66,10 @@ class Net {
   int H1, W1, Hf, Wf, Sd, nup;
   // layers
   ConvW stem; Bn bn0;
-  Block enc[4];
+  std::vector<Block> enc;            // 4 stages x cfg.blocks
   ConvW head_mu, head_lv; long head_pack_mu, head_pack_lv, head_pack_dg;
   ConvW dstem; Bn dbn0;
-  Block dec[5];
+  std::vector<Block> dec;            // nup stages x cfg.blocks (reference order: the upsampling block is the LAST of its stage)
   ConvW tail; long tail_bias; Bn bn_out;
   long stem_pack, tail_pack_f, tail_pack_d;   // packed-weight slots of the boundary layers (channel-padded)
 
@@ -89,7 +94,7 @@ class Net {
   hipStream_t wgrad_stream(hipStream_t s);      // stream the weight gradients are enqueued on
   int side_fork(hipStream_t s);                 // side stream waits for everything enqueued on s so far
   int side_join(hipStream_t s);                 // s waits for everything enqueued on the side stream so far
-  hipEvent_t blk_ev_[8] = {};                   // side-stream progress marks, one per block of a backward pass
+  hipEvent_t blk_ev_[16] = {};                   // side-stream progress marks, one per block of a backward pass
   int side_mark(int slot);                      // record mark `slot` on the side stream
   int side_wait_mark(int slot, hipStream_t s);  // s waits for mark `slot`
   int dt() const { return cfg.dtype; }
@@ -135,6 +140,9 @@ class Net {
   int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0);
   int bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s);
   float* bnf(const Bn& bn, char* base, int which) const;   // 0 mean 1 istd 2 scale 3 shift 4 A 5 B 6 C
+  const float* ones(char* base) const { return reinterpret_cast<const float*>(base + plan_.cvec); }
+  const float* zeros(char* base) const { return reinterpret_cast<const float*>(base + plan_.cvec) + 256; }
+  int fill_consts(char* base, hipStream_t s);
   int bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
                         hipStream_t s);
   BnBwdFinalizeArgs bwd_finalize_args(const Bn& bn, const float* params, float* grads, char* base, const float* partials, int nparts, int ny,

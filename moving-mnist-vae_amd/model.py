@@ -271,9 +271,11 @@ class VAE(nn.Module):
     def __init__(self, in_channels, intermediate_channels, decoder_out_channels=1, pixelcnn_out_channels=2,
                  z_dimension=32,
                  pixelcnn=True, only_pixelcnn=True, pixelcnn_layers=4, pixelcnn_activation="ReLu", nll=1, kl=1, mmd=0,
-                 require_rsample=True, sigma_decoder=0.1, input_image_size=64, compute_dtype=None):
+                 require_rsample=True, sigma_decoder=0.1, input_image_size=64, compute_dtype=None, blocks_per_stage=1):
         """Same arguments as the reference (model.py:259-262) plus ``compute_dtype`` ("bf16" default, or "f32";
-        also settable through the MMVAE_DTYPE environment variable): storage type of activations / MFMA inputs."""
+        also settable through the MMVAE_DTYPE environment variable): storage type of activations / MFMA inputs, and
+        ``blocks_per_stage`` (default 1 = the reference network): residual blocks per encoder / decoder stage of the deeper
+        build-defined variant (BASELINE configs[3]; include/mmvae.h: mmvae_net_create_ex)."""
         super().__init__()
         if pixelcnn or only_pixelcnn:
             raise NotImplementedError("only the plain conv-VAE path (pixelcnn=False, only_pixelcnn=False) is built; "
@@ -297,8 +299,9 @@ class VAE(nn.Module):
 
         L = lib()
         h = ctypes.c_void_p()
-        check(L.mmvae_net_create(ctypes.byref(h), in_channels, z_dimension, decoder_out_channels, input_image_size,
-                                 int(bool(require_rsample)), _DTYPES[dt]), "mmvae_net_create")
+        self.blocks_per_stage = int(blocks_per_stage)
+        check(L.mmvae_net_create_ex(ctypes.byref(h), in_channels, z_dimension, decoder_out_channels, input_image_size,
+                                    int(bool(require_rsample)), _DTYPES[dt], self.blocks_per_stage), "mmvae_net_create_ex")
         self.__dict__["_h"] = h
         n_params, n_bnf, dec_off = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         n_bni, dec_side = ctypes.c_int32(), ctypes.c_int32()
@@ -369,16 +372,27 @@ class VAE(nn.Module):
 
         conv("encoder.conv1.weight")
         for i in range(1, 5):
-            pre = f"encoder.layer{i}.0."
-            conv(pre + "downsample.0.weight"); conv(pre + "conv1.weight"); conv(pre + "conv2.weight")
+            j = 0
+            while f"encoder.layer{i}.{j}.conv1.weight" in byname:
+                pre = f"encoder.layer{i}.{j}."
+                if pre + "downsample.0.weight" in byname:
+                    conv(pre + "downsample.0.weight")
+                conv(pre + "conv1.weight"); conv(pre + "conv2.weight")
+                j += 1
         conv("encoder.conv_mu.weight")
         if self.require_rsample:
             conv("encoder.conv_logvar.weight")
         conv("decoder.conv1.weight")
         i = 1
         while f"decoder.uplayer{i}.0.conv1.weight" in byname:
-            pre = f"decoder.uplayer{i}.0."
-            conv(pre + "upsample.0.weight"); conv(pre + "conv1.weight"); conv(pre + "conv2.weight")
+            # reference construction order of a stage: the upsample shortcut, then the blocks in order (model.py:196-209)
+            j = 0
+            while f"decoder.uplayer{i}.{j}.conv1.weight" in byname:
+                j += 1
+            conv(f"decoder.uplayer{i}.{j - 1}.upsample.0.weight")
+            for b in range(j):
+                pre = f"decoder.uplayer{i}.{b}."
+                conv(pre + "conv1.weight"); conv(pre + "conv2.weight")
             i += 1
         conv("decoder.conv2.weight")
         w = byname["decoder.conv2.weight"]

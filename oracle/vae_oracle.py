@@ -51,11 +51,17 @@ def decoder_has_uplayer5(input_image_size: int) -> bool:
 
 
 def state_spec(in_channels: int, z: int, out_channels: int, input_image_size: int,
-               need_logvar: bool = True) -> List[Tuple[str, Tuple[int, ...], str]]:
+               need_logvar: bool = True, blocks: int = 1) -> List[Tuple[str, Tuple[int, ...], str]]:
     """(key, shape, kind) for every state_dict entry, in the reference's order.
 
     Encoder: model.py:89-112 (+ _make_layer :132-146, BasicBlock :26-37).
     Decoder: model.py:154-179 (+ _make_up_block :196-209, DeconvBottleneck :58-68).
+
+    ``blocks`` > 1 is the BUILD-DEFINED deeper variant (BASELINE configs[3]); parity UNPINNED by the reference, which
+    hard-codes one block per stage (:98-101, :164-170).  Encoder: exactly what ``_make_layer(blocks)`` builds (:140-144:
+    extra BasicBlocks with stride 1 and no downsample).  Decoder: ``_make_up_block(num_layer)`` puts the extra blocks FIRST
+    (:204-206) but builds them as DeconvBottleneck(in, out) whose 2x ConvTranspose2d main path cannot be added to its
+    identity shortcut; here an extra block keeps the stage's input shape: conv1x1 -> BN -> ReLU -> conv3x3 -> BN, + x, ReLU.
     """
     s: List[Tuple[str, Tuple[int, ...], str]] = []
     e = "encoder."
@@ -63,14 +69,16 @@ def state_spec(in_channels: int, z: int, out_channels: int, input_image_size: in
     s += _bn_entries(e + "bn1", 32)
     inpl = 32
     for li, planes in enumerate((32, 64, 128, 256), start=1):
-        p = f"{e}layer{li}.0."
-        s.append((p + "conv1.weight", (planes, inpl, 3, 3), "conv"))
-        s += _bn_entries(p + "bn1", planes)
-        s.append((p + "conv2.weight", (planes, planes, 3, 3), "conv"))
-        s += _bn_entries(p + "bn2", planes)
-        s.append((p + "downsample.0.weight", (planes, inpl, 1, 1), "conv"))
-        s += _bn_entries(p + "downsample.1", planes)
-        inpl = planes
+        for b in range(blocks):
+            p = f"{e}layer{li}.{b}."
+            s.append((p + "conv1.weight", (planes, inpl, 3, 3), "conv"))
+            s += _bn_entries(p + "bn1", planes)
+            s.append((p + "conv2.weight", (planes, planes, 3, 3), "conv"))
+            s += _bn_entries(p + "bn2", planes)
+            if b == 0:
+                s.append((p + "downsample.0.weight", (planes, inpl, 1, 1), "conv"))
+                s += _bn_entries(p + "downsample.1", planes)
+            inpl = planes
     s.append((e + "conv_mu.weight", (z, 256, 1, 1), "conv"))
     if need_logvar:
         s.append((e + "conv_logvar.weight", (z, 256, 1, 1), "conv"))
@@ -80,7 +88,13 @@ def state_spec(in_channels: int, z: int, out_channels: int, input_image_size: in
     cin = 128
     ups = [128, 64, 32, 16] + ([16] if decoder_has_uplayer5(input_image_size) else [])
     for ui, planes in enumerate(ups, start=1):
-        p = f"{d}uplayer{ui}.0."
+        for b in range(blocks - 1):                     # build-defined shape-preserving blocks, first in the stage
+            p = f"{d}uplayer{ui}.{b}."
+            s.append((p + "conv1.weight", (cin, cin, 1, 1), "conv"))
+            s += _bn_entries(p + "bn1", cin)
+            s.append((p + "conv2.weight", (cin, cin, 3, 3), "conv"))
+            s += _bn_entries(p + "bn2", cin)
+        p = f"{d}uplayer{ui}.{blocks - 1}."
         s.append((p + "conv1.weight", (planes, cin, 1, 1), "conv"))
         s += _bn_entries(p + "bn1", planes)
         s.append((p + "conv2.weight", (planes, planes, 4, 4), "convT"))
@@ -196,14 +210,20 @@ def encoder_forward(sd, x: torch.Tensor, training: bool = True, taps: Optional[d
     if taps is not None:
         taps[e + "stem"] = x
     for li in range(1, 5):
-        p = f"{e}layer{li}.0."
-        out = F.conv2d(x, sd[p + "conv1.weight"], None, 2, 1)     # :42 (conv3x3 stride 2, :14,:98-101)
-        out = F.relu(bn(out, p + "bn1"))                          # :43-44
-        out = F.conv2d(out, sd[p + "conv2.weight"], None, 1, 1)   # :46
-        out = bn(out, p + "bn2")                                  # :47
-        idn = F.conv2d(x, sd[p + "downsample.0.weight"], None, 2, 0)   # :50 (conv1x1 stride 2, :20,:135-138)
-        idn = bn(idn, p + "downsample.1")
-        x = F.relu(out + idn)                                     # :52-53
+        b = 0
+        while f"{e}layer{li}.{b}.conv1.weight" in sd:                 # one block in the reference (:98-101); more: build-defined
+            p = f"{e}layer{li}.{b}."
+            stride = 2 if b == 0 else 1
+            out = F.conv2d(x, sd[p + "conv1.weight"], None, stride, 1)    # :42 (conv3x3, stride 2 in block 0, :14,:98-101)
+            out = F.relu(bn(out, p + "bn1"))                          # :43-44
+            out = F.conv2d(out, sd[p + "conv2.weight"], None, 1, 1)   # :46
+            out = bn(out, p + "bn2")                                  # :47
+            idn = x                                                   # :40
+            if (p + "downsample.0.weight") in sd:
+                idn = F.conv2d(x, sd[p + "downsample.0.weight"], None, 2, 0)   # :50 (conv1x1 stride 2, :20,:135-138)
+                idn = bn(idn, p + "downsample.1")
+            x = F.relu(out + idn)                                     # :52-53
+            b += 1
         if taps is not None:
             taps[f"{e}layer{li}"] = x
     x = F.adaptive_avg_pool2d(x, (1, 1))                          # :123
@@ -229,7 +249,16 @@ def decoder_forward(sd, z: torch.Tensor, input_image_size: int, training: bool =
     x = F.relu(bn(x, d + "bn1"))                                            # :183-184
     n_up = 5 if decoder_has_uplayer5(input_image_size) else 4
     for ui in range(1, n_up + 1):
-        p = f"{d}uplayer{ui}.0."
+        b = 0
+        while (f"{d}uplayer{ui}.{b}.upsample.0.weight") not in sd:          # build-defined shape-preserving blocks (blocks > 1)
+            p = f"{d}uplayer{ui}.{b}."
+            out = F.conv2d(x, sd[p + "conv1.weight"])
+            out = F.relu(bn(out, p + "bn1"))
+            out = F.conv2d(out, sd[p + "conv2.weight"], None, 1, 1)
+            out = bn(out, p + "bn2")
+            x = F.relu(out + x)
+            b += 1
+        p = f"{d}uplayer{ui}.{b}."
         out = F.conv2d(x, sd[p + "conv1.weight"])                           # :73
         out = F.relu(bn(out, p + "bn1"))                                    # :74-75
         out = F.conv_transpose2d(out, sd[p + "conv2.weight"], None, 2, 1)   # :77 (k4 s2 p1, :62-65)
@@ -355,7 +384,7 @@ class OracleVAE(torch.nn.Module):
     def __init__(self, in_channels, intermediate_channels, decoder_out_channels=1, pixelcnn_out_channels=2,
                  z_dimension=32, pixelcnn=True, only_pixelcnn=True, pixelcnn_layers=4,
                  pixelcnn_activation="ReLu", nll=1, kl=1, mmd=0, require_rsample=True,
-                 sigma_decoder=0.1, input_image_size=64):
+                 sigma_decoder=0.1, input_image_size=64, blocks_per_stage=1):
         super().__init__()
         if pixelcnn or only_pixelcnn:
             raise NotImplementedError("oracle covers the plain conv-VAE path only")
@@ -372,7 +401,7 @@ class OracleVAE(torch.nn.Module):
         self.pixelcnn = None
         self.adjust = adjust_for(input_image_size)
         self.tiled_mmd = False
-        self._spec = state_spec(in_channels, z_dimension, decoder_out_channels, input_image_size, require_rsample)
+        self._spec = state_spec(in_channels, z_dimension, decoder_out_channels, input_image_size, require_rsample, blocks_per_stage)
         init = filled_state(self._spec, seed=0)
         for name, shape, kind in self._spec:
             parts = name.split(".")
