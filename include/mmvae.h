@@ -160,6 +160,12 @@ MMVAE_API int mmvae_quantise_normalise(const uint8_t* frames, int64_t n, const f
 MMVAE_API int mmvae_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* stream);
 
+/* The same update with the step count on the DEVICE (step_dev[0], a double, incremented by the call; bias corrections are computed
+ * from it inside the kernel): the form to capture in a HIP graph -- a captured launch replays its scalar arguments, so the host-side
+ * bias corrections of mmvae_adam_step would freeze at the captured step. */
+MMVAE_API int mmvae_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, double* step_dev, float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------ single ops (layer-level parity tests)
  * Conv2d / ConvTranspose2d with PyTorch weight layouts on NHWC activations of `dtype`:
  *   x [N,H,W,Cin], y [N,Ho,Wo,Cout];  weight f32 (Cout,Cin,k,k) for Conv2d, (Cin,Cout,k,k) for ConvTranspose2d.

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mmvae_normalise_labels": (c_int, [P, c_int64, c_float, c_float, P, P]),
     "mmvae_quantise_normalise": (c_int, [P, c_int64, P, c_int, c_float, c_float, P, P, P]),
     "mmvae_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P]),
+    "mmvae_adam_step_dev": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, P, c_float, P]),
     "mmvae_conv2d_fwd": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "mmvae_conv2d_dgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "mmvae_conv2d_wgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P]),

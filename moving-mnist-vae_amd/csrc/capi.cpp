@@ -189,6 +189,13 @@ int mmvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
   return launch_adam(a, S(st));
 }
 
+int mmvae_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                        double* step_dev, float grad_scale, void* st) {
+  if (!step_dev) { set_error("adam_step_dev: step counter required"); return MMVAE_ERR_ARG; }
+  AdamArgs a{p, g, m, v, (long)n, lr, b1, b2, eps, wd, 1.f, 1.f, grad_scale};
+  return launch_adam_dev(a, step_dev, S(st));
+}
+
 // ---- single ops
 static inline ConvGeom geom_for(int transposed, int Cin, int Cout, int k, int s, int p) {
   // Conv2d weight (Cout,Cin,k,k): D0=Cout (small side = y), D1=Cin.  ConvT weight (Cin,Cout,k,k): D0=Cin (small side = x), D1=Cout.

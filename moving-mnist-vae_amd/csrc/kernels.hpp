@@ -268,6 +268,7 @@ int launch_mmd_bwd(const float* x, const float* y, int n, int d, float coef, con
 // ---------------------------------------------------------------- optimiser / misc
 struct AdamArgs { float* p; const float* g; float* m; float* v; long n; float lr, beta1, beta2, eps, weight_decay; float bc1, bc2; float grad_scale; };
 int launch_adam(const AdamArgs& a, hipStream_t s);
+int launch_adam_dev(const AdamArgs& a, double* state, hipStream_t s);   // step count on the device (graph capture): bc1 / bc2 ignored
 // labels (int64) -> image T [(l - mean)/std] (+ f32 copy for the Gaussian target)
 int launch_normalise(int dt, const long long* labels, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s);
 int launch_quantise_normalise(const unsigned char* frames, long n, const float* centres, int q, float mean, float stdv,

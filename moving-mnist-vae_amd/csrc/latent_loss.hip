@@ -477,6 +477,36 @@ int launch_adam(const AdamArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(adam_kernel, dim3(rblocks(a.n, 2048)), dim3(256), 0, s, a);
   return check_launch("adam");
 }
+// Graph-capturable form: the step count lives on the device (a captured launch replays its scalar arguments, so host-side bias
+// corrections would freeze).  state[0] = step count (as a double), incremented first; bias corrections from it.
+__global__ void adam_dev_kernel(AdamArgs a, double* state) {
+  __shared__ float sbc[2];
+  if (threadIdx.x == 0) {
+    const double t = state[0] + 1.0;          // every block computes the same corrections from the not-yet-incremented count
+    sbc[0] = (float)(1.0 - pow((double)a.beta1, t));
+    sbc[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+  }
+  __syncthreads();
+  const float bc1 = sbc[0], bc2 = sbc[1];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+    float g = a.g[i] * a.grad_scale;
+    float p = a.p[i];
+    if (a.weight_decay != 0.f) g += a.weight_decay * p;
+    float m = a.m[i], v = a.v[i];
+    m = m + (g - m) * (1.0f - a.beta1);
+    v = v * a.beta2 + (1.0f - a.beta2) * g * g;
+    const float denom = sqrtf(v) / bc2 + a.eps;
+    p = p - (a.lr / bc1) * (m / denom);
+    a.p[i] = p; a.m[i] = m; a.v[i] = v;
+  }
+}
+__global__ void adam_tick_kernel(double* state) { state[0] += 1.0; }
+int launch_adam_dev(const AdamArgs& a, double* state, hipStream_t s) {
+  if (a.n <= 0) return MMVAE_OK;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(rblocks(a.n, 2048)), dim3(256), 0, s, a, state);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, state);      // after every block has read the old count
+  return check_launch("adam_dev");
+}
 
 // ---------------------------------------------------------------- input normalisation (main.py:383-387)
 template <typename T>

@@ -629,7 +629,9 @@ class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam (defaults of main.py:468) as ONE HIP kernel over the model's flat parameter buffer.
     Drop-in: ``FusedAdam(list(model.parameters()))``; ``state_dict()`` has the torch.optim.Adam layout."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+        """capturable=True keeps the step count on the device (mmvae_adam_step_dev), so that a train step captured in a HIP graph
+        (torch.cuda.graph) replays with advancing bias corrections; the eager default computes them on the host."""
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         owner = getattr(params[0], "_mmvae_owner", None)
@@ -639,6 +641,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._model = weakref.ref(model)
         self._t = 0
         self._m = self._v = None
+        self._capturable = bool(capturable)
+        self._step_dev = None
 
     def _moments(self, model):
         flat = model._flat
@@ -705,6 +709,13 @@ class FusedAdam(torch.optim.Optimizer):
         m, v = self._moments(model)
         self._t += 1
         b1, b2 = g["betas"]
+        if self._capturable:
+            if self._step_dev is None or self._step_dev.device != model._flat.device:
+                self._step_dev = torch.full((1,), float(self._t - 1), dtype=torch.float64, device=model._flat.device)
+            check(lib().mmvae_adam_step_dev(ptr(model._flat), ptr(G), ptr(m), ptr(v), model._n_params, float(g["lr"]), float(b1), float(b2),
+                                            float(g["eps"]), float(g["weight_decay"]), ptr(self._step_dev), scale, _stream()),
+                  "mmvae_adam_step_dev")
+            return loss            # (state["step"] mirrors the host count of step() calls; under graph replay read _step_dev)
         bc1 = 1.0 - b1 ** self._t
         bc2s = math.sqrt(1.0 - b2 ** self._t)
         check(lib().mmvae_adam_step(ptr(model._flat), ptr(G), ptr(m), ptr(v), model._n_params, float(g["lr"]), float(b1), float(b2),

@@ -94,3 +94,73 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_train_step_is_hipgraph_capturable_and_replays_the_eager_trajectory(oracle):
+    """include/mmvae.h promises stream-ordered, graph-capturable entry points (the library's side stream forks from and joins the
+    caller's stream with events, nothing allocates or synchronises).  One whole train step -- labels -> forward -> loss -> backward
+    (side-stream weight gradients included) -> Adam with its step count on the device -- is captured once with torch.cuda.graph
+    and replayed three times on new inputs; losses and parameters must follow the eager run of the same three steps (f32 mode)."""
+    import types
+    M = _M()
+    main = importlib.import_module("moving-mnist-vae_amd.main")
+    dev = torch.device("cuda")
+    N, z = 40, 32
+    batches = [oracle.synthetic_labels(N, 64, seed=60 + i).to(dev) for i in range(3)]
+    g = torch.Generator().manual_seed(2)
+    noise = [(torch.randn(N, z, 1, 1, generator=g).to(dev), torch.randn(N, z, generator=g).to(dev)) for _ in range(3)]
+    args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
+
+    def fresh():
+        torch.manual_seed(5)
+        m = M.VAE(1, 32, 1, 2, z, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype="f32").to(dev).train()
+        return m, M.FusedAdam(list(m.parameters()), capturable=True)
+
+    def one_step(m, opt, labels):
+        image, target = main.prepare_batch(m, labels, dev, args, oracle.DATA_MEAN, oracle.DATA_STD)
+        mu, lv, enc, rec = m(image)
+        loss = m.loss(target, mu, lv, enc, rec, dev, args, deferred=True)[0]
+        opt.zero_grad()                       # main.py:397-399
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    # eager reference
+    m, opt = fresh()
+    eager = []
+    for i in range(3):
+        m.injected_eps, m.injected_true_samples = noise[i]
+        eager.append(one_step(m, opt, batches[i]).item())
+    p_eager = {k: v.detach().clone() for k, v in m.named_parameters()}
+    # captured: static input buffers, warm-up on a side stream (creates the library's streams / events), state restored, capture
+    m, opt = fresh()
+    lab, e_s, t_s = batches[0].clone(), noise[0][0].clone(), noise[0][1].clone()
+    m.injected_eps, m.injected_true_samples = e_s, t_s
+    snap = (m._flat.detach().clone(), m._bnf.detach().clone(), m._bni.detach().clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        one_step(m, opt, lab)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        m._flat.copy_(snap[0]); m._bnf.copy_(snap[1]); m._bni.copy_(snap[2])
+        opt._m.zero_(); opt._v.zero_(); opt._step_dev.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = one_step(m, opt, lab)
+    replayed = []
+    for i in range(3):
+        lab.copy_(batches[i]); e_s.copy_(noise[i][0]); t_s.copy_(noise[i][1])
+        graph.replay()
+        replayed.append(out.item())
+    torch.cuda.synchronize()
+    assert int(opt._step_dev.item()) == 3
+    for a, b in zip(replayed, eager):
+        assert abs(a - b) <= 1e-6 * abs(b), (replayed, eager)
+    for k, v in m.named_parameters():
+        if k == "decoder.conv2.bias":
+            continue      # analytically-zero gradient (a bias in front of a BatchNorm): Adam turns rounding noise into +-lr steps
+        # not bit-for-bit: a few reductions end in float atomics (summation order), and Adam's early steps turn last-bit
+        # differences of near-zero gradient elements into visible ones (1.6e-4 of the tensor's scale measured)
+        assert (v - p_eager[k]).abs().max().item() <= 1e-3 * max(p_eager[k].abs().max().item(), 1e-3), k
