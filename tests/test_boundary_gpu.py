@@ -125,13 +125,19 @@ def test_train_step_is_hipgraph_capturable_and_replays_the_eager_trajectory(orac
         opt.step()
         return loss.detach()
 
-    # eager reference
-    m, opt = fresh()
-    eager = []
-    for i in range(3):
-        m.injected_eps, m.injected_true_samples = noise[i]
-        eager.append(one_step(m, opt, batches[i]).item())
-    p_eager = {k: v.detach().clone() for k, v in m.named_parameters()}
+    # eager reference, twice: the run-to-run spread is the yardstick (a few reductions end in float atomics, and Adam's first steps
+    # turn last-bit differences of near-zero gradient elements into visible parameter differences)
+    def eager_run():
+        m, opt = fresh()
+        ls = []
+        for i in range(3):
+            m.injected_eps, m.injected_true_samples = noise[i]
+            ls.append(one_step(m, opt, batches[i]).item())
+        return ls, {k: v.detach().clone() for k, v in m.named_parameters()}
+
+    eager, p_eager = eager_run()
+    eager2, p_eager2 = eager_run()
+    spread = {k: (p_eager[k] - p_eager2[k]).abs().max().item() for k in p_eager}
     # captured: static input buffers, warm-up on a side stream (creates the library's streams / events), state restored, capture
     m, opt = fresh()
     lab, e_s, t_s = batches[0].clone(), noise[0][0].clone(), noise[0][1].clone()
@@ -158,9 +164,9 @@ def test_train_step_is_hipgraph_capturable_and_replays_the_eager_trajectory(orac
     assert int(opt._step_dev.item()) == 3
     for a, b in zip(replayed, eager):
         assert abs(a - b) <= 1e-6 * abs(b), (replayed, eager)
+    worst = 0.0
     for k, v in m.named_parameters():
-        if k == "decoder.conv2.bias":
-            continue      # analytically-zero gradient (a bias in front of a BatchNorm): Adam turns rounding noise into +-lr steps
-        # not bit-for-bit: a few reductions end in float atomics (summation order), and Adam's early steps turn last-bit
-        # differences of near-zero gradient elements into visible ones (1.6e-4 of the tensor's scale measured)
-        assert (v - p_eager[k]).abs().max().item() <= 1e-3 * max(p_eager[k].abs().max().item(), 1e-3), k
+        d = (v - p_eager[k]).abs().max().item()
+        worst = max(worst, d)
+        assert d <= 3.0 * spread[k] + 2e-6, (k, d, spread[k])
+    print(f"\ngraph replay vs eager: losses {replayed} vs {eager}; max parameter difference {worst:.3e} (eager vs eager: {max(spread.values()):.3e})")
