@@ -258,7 +258,8 @@ def main():
                          "build-defined variant (2 residual blocks per stage), z=512, 512 clips")
     ap.add_argument("--clips", type=int, default=None, help="clips (of 20 frames) per GPU per step (default: 256 for c2, 512 for c4)")
     ap.add_argument("--z", type=int, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8 = BASELINE configs[4]: bf16 storage, fp8 (e4m3) MFMA in the forward pass of the deep layers (tests/test_fp8_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true", help="BatchNorm statistics over the global batch (default: per rank)")

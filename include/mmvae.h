@@ -41,6 +41,10 @@ extern "C" {
 
 #define MMVAE_F32 0
 #define MMVAE_BF16 1
+#define MMVAE_FP8 2     /* network handle only (BASELINE configs[4]): bf16 storage, but the forward convolutions of the deep layers (channel
+                           counts that are multiples of 64, every one followed by a BatchNorm) run on v_mfma_f32_16x16x32_fp8_fp8: OCP e4m3
+                           weights (static power-of-two scale per layer, absorbed exactly by the BatchNorm) x e4m3 activations (quantised
+                           behind the fused BN+ReLU), f32 accumulation and statistics; the backward pass stays bf16 (straight-through) */
 
 MMVAE_API int mmvae_abi_version(void);
 MMVAE_API const char* mmvae_last_error(void);          /* host string, valid until the next failing call on this thread */

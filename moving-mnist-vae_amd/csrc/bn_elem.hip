@@ -175,7 +175,8 @@ __global__ void bn_finalize_kernel(BnFinalizeArgs a) {
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    const double istd = 1.0 / sqrt(var + (double)a.eps);
+    const double isc = (double)a.in_scale;
+    const double istd = 1.0 / sqrt(var + (double)a.eps * isc * isc);
     const float g = a.gamma ? a.gamma[c] : 1.f, b = a.beta ? a.beta[c] : 0.f;
     a.mean[c] = (float)mean;
     a.istd[c] = (float)istd;
@@ -183,8 +184,8 @@ __global__ void bn_finalize_kernel(BnFinalizeArgs a) {
     a.scale[c] = sc;
     a.shift[c] = (float)((double)b - mean * (double)g * istd);
     if (a.running_mean) {
-      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-      a.running_mean[c] = (float)((1.0 - (double)a.momentum) * (double)a.running_mean[c] + (double)a.momentum * mean);
+      const double unbiased = (n > 1.0 ? var * n / (n - 1.0) : var) / (isc * isc);
+      a.running_mean[c] = (float)((1.0 - (double)a.momentum) * (double)a.running_mean[c] + (double)a.momentum * mean / isc);
       a.running_var[c] = (float)((1.0 - (double)a.momentum) * (double)a.running_var[c] + (double)a.momentum * unbiased);
     }
     if (c == 0 && a.nbt) *a.nbt += 1;
@@ -197,18 +198,18 @@ int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
 }
 
 __global__ void bn_eval_affine_kernel(const float* g, const float* b, const float* rm, const float* rv, float eps, int C,
-                                      float* scale, float* shift) {
+                                      float* scale, float* shift, float in_scale) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     const float istd = 1.0f / sqrtf(rv[c] + eps);
     const float sc = g[c] * istd;
-    scale[c] = sc;
+    scale[c] = sc / in_scale;              // the input is y' = in_scale * y
     shift[c] = b[c] - rm[c] * sc;
   }
 }
 int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
-                          float* scale, float* shift, hipStream_t s) {
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, eps, C, scale, shift);
+                          float* scale, float* shift, hipStream_t s, float in_scale) {
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, eps, C, scale, shift, in_scale);
   return check_launch("bn_eval_affine");
 }
 

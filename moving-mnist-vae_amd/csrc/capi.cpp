@@ -31,8 +31,9 @@ int mmvae_net_create_ex(mmvae_net** out, int in_channels, int z, int out_channel
   if (!(out_channels == 1 || out_channels == 2 || out_channels == 3 || out_channels == 4 || out_channels == 8)) {
     set_error("decoder_out_channels=%d unsupported (1,2,3,4,8)", out_channels); return MMVAE_ERR_UNSUPPORTED; }
   if (image_size < 9 || image_size > 64) { set_error("input_image_size=%d unsupported (9..64)", image_size); return MMVAE_ERR_UNSUPPORTED; }
-  if (dtype != MMVAE_F32 && dtype != MMVAE_BF16) { set_error("dtype=%d unsupported", dtype); return MMVAE_ERR_ARG; }
-  NetCfg c{in_channels, z, out_channels, image_size, need_logvar ? 1 : 0, dtype, blocks_per_stage};
+  if (dtype != MMVAE_F32 && dtype != MMVAE_BF16 && dtype != MMVAE_FP8) { set_error("dtype=%d unsupported", dtype); return MMVAE_ERR_ARG; }
+  // MMVAE_FP8: bf16 storage everywhere, fp8 (e4m3) MFMA in the forward pass of the deep layers
+  NetCfg c{in_channels, z, out_channels, image_size, need_logvar ? 1 : 0, dtype == MMVAE_FP8 ? MMVAE_BF16 : dtype, blocks_per_stage, dtype == MMVAE_FP8 ? 1 : 0};
   mmvae_net* h = new (std::nothrow) mmvae_net;
   if (!h) return MMVAE_ERR_ARG;
   h->net = new (std::nothrow) Net(c);

@@ -471,7 +471,7 @@ static int try_deep(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
   b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate;
   b.N = a.N; b.Hi = a.Hi; b.Wi = a.Wi; b.Cin = a.Cin; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = a.SI; b.SO = a.SO;
-  b.nphase = a.nphase;
+  b.nphase = a.nphase; b.fp8 = a.fp8;
   for (int p = 0; p < a.nphase; ++p) {
     const Phase& ph = a.phases[p];
     if (ph.ntaps <= 0) return 0;
@@ -516,6 +516,14 @@ static int launch_x2_separately(int dt, int out_dt, const GatherArgs& a, hipStre
 
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
+  if (a.fp8) {
+    // fp8 forward convolutions exist in the deep-layer kernel only (the packed weights are e4m3 bytes: no other kernel can read them)
+    if (dt != DT_BF16 || out_dt != DT_BF16 || a.x2 || a.accumulate) { set_error("gather_gemm: fp8 needs the bf16 forward path"); return MMVAE_ERR_UNSUPPORTED; }
+    a.cin_vecs = a.Cin / VE;
+    const int rc = try_deep(dt, out_dt, a, s);
+    if (rc == 0) { set_error("gather_gemm: fp8 layer Cin=%d Cout=%d is not eligible for the deep-layer kernel", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }
+    return rc;
+  }
   if (a.x2) {
     static const bool merge = [] { const char* e = getenv("MMVAE_X2_MERGE"); return !(e && e[0] == '0'); }();
     int rc = (merge && !conv_force_v1()) ? try_patch(dt, out_dt, a, s) : 0;
@@ -888,8 +896,12 @@ __global__ void pack_kernel(PackArgs a) {
 }
 
 struct PackJob {
-  const float* src; void* dst; int cols, K, ntaps, s_col, s_k, cols_valid, K_valid; float scale; unsigned char tap_off[28];
+  const float* src; void* dst; int cols, K, ntaps, s_col, s_k, cols_valid, K_valid; float scale; unsigned char tap_off[27]; unsigned char fp8;
 };
+__device__ __forceinline__ unsigned char f32_to_e4m3(float v) {
+  v = fminf(fmaxf(v, -448.f), 448.f);
+  return (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xff);
+}
 constexpr int kPackJobsPerLaunch = 48;
 struct PackMulti { int njobs; int pad; PackJob jobs[kPackJobsPerLaunch]; };
 
@@ -904,7 +916,8 @@ __global__ void pack_multi_kernel(PackMulti m) {
     const int col = (int)(q / a.ntaps);
     const bool real = (a.cols_valid <= 0 || col < a.cols_valid) && (a.K_valid <= 0 || k < a.K_valid);
     const float v = real ? a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale : 0.f;
-    Elem<T>::store(reinterpret_cast<T*>(a.dst) + i, v);
+    if (a.fp8) reinterpret_cast<unsigned char*>(a.dst)[i] = f32_to_e4m3(v);
+    else Elem<T>::store(reinterpret_cast<T*>(a.dst) + i, v);
   }
 }
 
@@ -933,13 +946,14 @@ int launch_pack(int dt, const PackArgs& a, hipStream_t s) {
   const long total = (long)a.cols * a.ntaps * a.K;
   if (total <= 0) return MMVAE_OK;
   if (g_pack_batching) {
-    if (g_pack_n >= 256 || a.ntaps > 28) { set_error("pack batch overflow"); return MMVAE_ERR_ARG; }
+    if (g_pack_n >= 256 || a.ntaps > 27) { set_error("pack batch overflow"); return MMVAE_ERR_ARG; }
     PackJob& j = g_pack_jobs[g_pack_n++];
     j.src = a.src; j.dst = a.dst; j.cols = a.cols; j.K = a.K; j.ntaps = a.ntaps; j.s_col = a.s_col; j.s_k = a.s_k;
-    j.cols_valid = a.cols_valid; j.K_valid = a.K_valid; j.scale = a.scale;
+    j.cols_valid = a.cols_valid; j.K_valid = a.K_valid; j.scale = a.scale; j.fp8 = (unsigned char)(a.fp8 ? 1 : 0);
     for (int t = 0; t < a.ntaps; ++t) j.tap_off[t] = (unsigned char)a.tap_off[t];
     return MMVAE_OK;
   }
+  if (a.fp8) { set_error("pack: fp8 packing is available in batched mode only"); return MMVAE_ERR_UNSUPPORTED; }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (dt == DT_F32) hipLaunchKernelGGL((pack_kernel<float>), dim3(blocks), dim3(256), 0, s, a);

@@ -34,28 +34,28 @@ static int up_phases(int k, int s, int p, UpPhase* out) {
 }
 
 
-int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s) {
+int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale, int fp8) {
   PackArgs a; std::memset(&a, 0, sizeof(a));
   const int kk = g.k * g.k;
   if (kk > kMaxTaps) { set_error("pack_down: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
   a.src = w; a.dst = dst;
-  a.cols = g.D0; a.K = g.D1; a.ntaps = kk; a.s_col = g.D1 * kk; a.s_k = kk; a.scale = 1.f;
+  a.cols = g.D0; a.K = g.D1; a.ntaps = kk; a.s_col = g.D1 * kk; a.s_k = kk; a.scale = scale; a.fp8 = fp8;
   for (int t = 0; t < kk; ++t) a.tap_off[t] = t;
   return launch_pack(dt, a, s);
 }
 
-int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s) {
+int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale, int fp8) {
   if (g.s > 2 || g.k * g.k > kMaxTaps) { set_error("pack_up: k=%d s=%d unsupported", g.k, g.s); return MMVAE_ERR_UNSUPPORTED; }
   UpPhase ph[4];
   const int np = up_phases(g.k, g.s, g.p, ph);
   const int kk = g.k * g.k;
-  const long e = (long)dtype_size(dt);
+  const long e = fp8 ? 1 : (long)dtype_size(dt);
   long off = 0;
   for (int i = 0; i < np; ++i) {
     if (ph[i].ntaps == 0) continue;
     PackArgs a; std::memset(&a, 0, sizeof(a));
     a.src = w; a.dst = static_cast<char*>(dst) + off * e;
-    a.cols = g.D1; a.K = g.D0; a.ntaps = ph[i].ntaps; a.s_col = kk; a.s_k = g.D1 * kk; a.scale = 1.f;
+    a.cols = g.D1; a.K = g.D0; a.ntaps = ph[i].ntaps; a.s_col = kk; a.s_k = g.D1 * kk; a.scale = scale; a.fp8 = fp8;
     for (int t = 0; t < ph[i].ntaps; ++t) a.tap_off[t] = ph[i].kh[t] * g.k + ph[i].kw[t];
     MM_TRY(launch_pack(dt, a, s));
     off += (long)g.D1 * ph[i].ntaps * g.D0;
@@ -68,6 +68,7 @@ int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N
   GatherArgs a; std::memset(&a, 0, sizeof(a));
   if (g.k * g.k > kMaxTaps) { set_error("run_down: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
   if (x2.x2) { a.x2 = x2.x2; a.w2 = x2.w2; a.Cin2 = x2.Cin2; a.x2_ph = 0; a.x2_pw = 0; }
+  a.fp8 = x2.fp8;
   a.x = L; a.w = packed; a.y = S;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hl; a.Wi = Wl; a.Cin = g.D1; a.Ho = Hs; a.Wo = Ws; a.Cout = g.D0; a.SI = g.s; a.SO = 1;
@@ -83,6 +84,7 @@ int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* 
   if (g.s > 2 || g.k * g.k > kMaxTaps) { set_error("run_up: k=%d s=%d unsupported", g.k, g.s); return MMVAE_ERR_UNSUPPORTED; }
   GatherArgs a; std::memset(&a, 0, sizeof(a));
   if (x2.x2) { a.x2 = x2.x2; a.w2 = x2.w2; a.Cin2 = x2.Cin2; a.x2_ph = 0; a.x2_pw = 0; }
+  a.fp8 = x2.fp8;
   a.x = S; a.w = packed; a.y = L;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hs; a.Wi = Ws; a.Cin = g.D0; a.Ho = Hl; a.Wo = Wl; a.Cout = g.D1; a.SI = 1; a.SO = g.s;
@@ -106,7 +108,7 @@ int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* 
 
 int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                  const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s,
-                 float* scratch) {
+                 float* scratch, float scale) {
   WgradArgs a; std::memset(&a, 0, sizeof(a));
   const int kk = g.k * g.k;
   if (kk > 25) { set_error("wgrad: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
@@ -114,7 +116,7 @@ int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws
   a.proP_scale = proP_s; a.proP_shift = proP_b; a.proP_relu = proP_relu;
   a.proG_scale = proG_s; a.proG_shift = proG_b; a.proG_relu = proG_relu;
   a.N = N; a.Hp = Hs; a.Wp = Ws; a.Ca = g.D0; a.Hg = Hl; a.Wg = Wl; a.Cb = g.D1; a.Cb_valid = g.D1;
-  a.stride = g.s; a.pad = g.p; a.ksz = g.k; a.sA = g.D1 * kk; a.sB = kk; a.ntaps = kk; a.scale = 1.f;
+  a.stride = g.s; a.pad = g.p; a.ksz = g.k; a.sA = g.D1 * kk; a.sB = kk; a.ntaps = kk; a.scale = scale;
   for (int t = 0; t < kk; ++t) a.tap_off[t] = t;
   return launch_wgrad(dt, a, s);
 }

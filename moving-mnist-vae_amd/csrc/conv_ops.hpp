@@ -12,17 +12,21 @@ struct ConvGeom { int D0, D1, k, s, p; };
 
 inline int conv_down_size(int H, int k, int s, int p) { return (H + 2 * p - k) / s + 1; }
 // packed element counts (both equal numel(weight)); 16-byte alignment is the caller's job
-int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s);
-int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s);
+// scale multiplies the weights (fp8 layers: the static per-layer scale); fp8 = 1 writes e4m3 bytes (batched packing only)
+int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0);
+int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0);
 // x2 / w2 / Cin2 (optional): a second tensor on the q grid (= S for run_down, = the S-resolution grid for run_up) whose 1x1
 // convolution with the packed [Cout][Cin2] matrix w2 is added into the result (phase (0,0) of run_up) in the same kernel.
-struct SecondSrc { const void* x2 = nullptr; const void* w2 = nullptr; int Cin2 = 0; };
+struct SecondSrc {
+  const void* x2 = nullptr; const void* w2 = nullptr; int Cin2 = 0;
+  int fp8 = 0;             // the forward conv runs on the fp8 MFMA (e4m3 packed weights)
+};
 int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
                 const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s, const SecondSrc& x2 = SecondSrc());
 int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* S, int Hs, int Ws, void* L, int Hl, int Wl,
               const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s, const SecondSrc& x2 = SecondSrc());
 int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                  const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s,
-                 float* scratch = nullptr);
+                 float* scratch = nullptr, float scale = 1.f);
 
 }  // namespace mmvae

@@ -140,8 +140,8 @@ size_t deep_conv_lds_bytes(const DeepArgs& a, int dt) {
   const size_t es = dtype_size(dt);
   const int CT = a.ct16 * 16;
   const int TPX = (8 / (a.ct16 / 4)) * a.npt * 16;
-  const size_t pitch = (size_t)a.Cin * es + 16;
-  return (size_t)(a.ipt * a.Hi * a.Wi + 1) * pitch + (size_t)2 * CT * 9 * 16 + (size_t)a.ntaps_all * TPX * 2 + 1024 * 4;
+  const size_t pitch = (size_t)a.Cin * (a.fp8 ? 1 : es) + 16;
+  return (size_t)(a.ipt * a.Hi * a.Wi + 1) * pitch + (size_t)2 * CT * (a.fp8 ? 5 : 9) * 16 + (size_t)a.ntaps_all * TPX * 2 + 1024 * 4;
 }
 
 int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s) {

@@ -36,6 +36,7 @@ struct GatherArgs {
   // q grid itself ([N][Hq][Wq][Cin2] of T, no halo).  Merges the two data gradients that meet at a residual block's input
   // (3x3 / 4x4 main path + 1x1 shortcut) into one kernel: no read-modify-write of the sum.
   const void* x2; const void* w2; int Cin2, x2_ph, x2_pw;
+  int fp8;                 // 1: w holds e4m3 bytes (same [cout][tap][cin] order); only the deep-layer kernel takes it (else an error)
 };
 // out_dt: dtype of y (may be DT_F32 while x/w are bf16).  Returns the number of stats partial rows (>0) or an error (<0).
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s);
@@ -139,6 +140,7 @@ struct DeepArgs {
   int nphase; DeepPhase phases[kMaxPhases]; Tap taps[kMaxTaps]; int ntaps_all;
   int ipt, ntiles;             // whole images per tile, tiles
   int ct16, npt;               // cout tile / 16 (4 or 8), 16-pixel column tiles per wave
+  int fp8;                     // w is e4m3 bytes, activations are quantised in LDS: v_mfma_f32_16x16x32_fp8_fp8 (forward convs, bf16 storage)
 };
 size_t deep_conv_lds_bytes(const DeepArgs& a, int dt);
 int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
@@ -150,6 +152,7 @@ int conv_xcd_walk();      // MMVAE_XCD (default 1): XCD-aware tile order in the 
 struct PackArgs {
   const float* src; void* dst; int cols, K, ntaps; int s_col, s_k; int tap_off[kMaxTaps]; float scale;
   int cols_valid, K_valid;   // >0: columns / k beyond these are written as zero (channel padding), source not read
+  int fp8;                   // 1: dst receives OCP e4m3 bytes (one per element) instead of T
 };
 int launch_pack(int dt, const PackArgs& a, hipStream_t s);
 // Batched packing: between pack_batch_begin() and pack_batch_flush() every launch_pack() call is only recorded;
@@ -189,6 +192,8 @@ int chan_stats_parts(long npix, int C);
 int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials, hipStream_t s);
 // training finalize: partials -> mean/istd/scale/shift; running stats update (momentum, unbiased var); nbt += 1
 struct BnFinalizeArgs {
+  float in_scale = 1.f;      // the statistics are of y' = in_scale * y (fp8 layers: statically scaled weights): eps and the running
+                             // statistics are converted, so the BatchNorm of y' is exactly the BatchNorm of y
   const float* partials; int nparts; int C; double count;
   const float* gamma; const float* beta; float* running_mean; float* running_var; long long* nbt;
   float* mean; float* istd; float* scale; float* shift; float momentum, eps;
@@ -197,7 +202,7 @@ int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 int launch_partial_rowsum(const float* partials, int nparts, int width, float* out, hipStream_t s, int row_stride = 0);   // SyncBN: [nparts][width (stride row_stride)] -> [width]
 // eval: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
 int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
-                          float* scale, float* shift, hipStream_t s);
+                          float* scale, float* shift, hipStream_t s, float in_scale = 1.f);
 // out = relu(a*sa + ba + b*sb + bb)   (NHWC, T)
 int launch_join_fwd(int dt, const void* a, const float* sa, const float* ba, const void* b, const float* sb, const float* bb,
                     void* out, long npix, int C, hipStream_t s);

@@ -1,6 +1,7 @@
 #include "vae_net.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -25,13 +26,19 @@ void Net::add_entry(const std::string& name, std::initializer_list<int> shape, i
   entries.push_back(e);
 }
 
-ConvW Net::add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack) {
-  ConvW w; w.off = n_params; w.D0 = D0; w.D1 = D1; w.k = k; w.s = s; w.p = p; w.packD = w.packU = -1;
+ConvW Net::add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack, bool transposed) {
+  ConvW w; w.off = n_params; w.D0 = D0; w.D1 = D1; w.k = k; w.s = s; w.p = p; w.packD = w.packU = -1; w.tr = transposed;
   add_entry(name, {D0, D1, k, k}, EK_PARAM, n_params);
   const long numel = (long)D0 * D1 * k * k;
   n_params += numel;
   if (numel > max_w) max_w = numel;
   if (pack) { w.packD = n_packed; n_packed += align_up(numel, 8); w.packU = n_packed; n_packed += align_up(numel, 8); }
+  if (cfg.fp8 && pack && D0 >= 64 && D1 >= 64 && D0 % 64 == 0 && D1 % 64 == 0) {
+    // static scale: PyTorch's default init is U(+-1/sqrt(D1*k*k)) for both weight layouts; bring that bound to ~16..32 (e4m3 normal range)
+    w.fp8 = true;
+    int e = 0; while ((float)(1 << e) < 16.f * std::sqrt((float)D1 * k * k)) ++e;
+    w.wscale = (float)(1 << e);
+  }
   return w;
 }
 
@@ -88,7 +95,7 @@ Net::Net(const NetCfg& c) : cfg(c) {
   tail_pack_d = n_packed; n_packed += 16L * 9 * 8;
   // ---- decoder (model.py:154-179)
   dec_param_off = n_params;
-  dstem = add_conv("decoder.conv1.weight", c.z, 128, 2, 2, 0, true);   // k2 s1 p0 on a 1x1 input == k2 s2 p0
+  dstem = add_conv("decoder.conv1.weight", c.z, 128, 2, 2, 0, true, true);   // k2 s1 p0 on a 1x1 input == k2 s2 p0
   dbn0 = add_bn("decoder.bn1", 128);
   nup = S > 32 ? 5 : 4;                                               // :169
   const int ups[5] = {128, 64, 32, 16, 16};
@@ -111,9 +118,9 @@ Net::Net(const NetCfg& c) : cfg(c) {
         B.Cin = cin; B.C = ups[i]; B.Hin = B.Win = H; B.Hmid = B.Wmid = H; B.Hout = B.Wout = 2 * H;
         B.c1 = add_conv(p + "conv1.weight", ups[i], cin, 1, 1, 0, true);        // 1x1 (:60)
         B.b1 = add_bn(p + "bn1", ups[i]);
-        B.c2 = add_conv(p + "conv2.weight", ups[i], ups[i], 4, 2, 1, true);      // ConvT k4 s2 p1 (:62-65)
+        B.c2 = add_conv(p + "conv2.weight", ups[i], ups[i], 4, 2, 1, true, true);      // ConvT k4 s2 p1 (:62-65)
         B.b2 = add_bn(p + "bn2", ups[i]);
-        B.cs = add_conv(p + "upsample.0.weight", cin, ups[i], 4, 2, 1, true);    // ConvT k4 s2 p1 (:198-201)
+        B.cs = add_conv(p + "upsample.0.weight", cin, ups[i], 4, 2, 1, true, true);    // ConvT k4 s2 p1 (:198-201)
         B.bs = add_bn(p + "upsample.1", ups[i]);
         cin = ups[i]; H = 2 * H;
       }
@@ -187,17 +194,21 @@ float* Net::bnf(const Bn& bn, char* base, int which) const {
 // ------------------------------------------------------------------------------------------------ conv helpers
 static inline ConvGeom geom(const ConvW& w) { return ConvGeom{w.D0, w.D1, w.k, w.s, w.p}; }
 
+// fwd = 1: this pack feeds the conv's FORWARD direction (an fp8 layer then gets e4m3 bytes); every pack of an fp8 layer is scaled
+// the pack that feeds a conv's FORWARD direction (down for Conv2d, up for ConvTranspose2d) is e4m3 bytes on an fp8 layer; every pack
+// of an fp8 layer carries its weight scale
 int Net::pack_down(const ConvW& w, const float* params, char* base, hipStream_t s) {
-  return op_pack_down(dt(), geom(w), params + w.off, base + plan_.packed + w.packD * (long)esz(), s);
+  return op_pack_down(dt(), geom(w), params + w.off, base + plan_.packed + w.packD * (long)esz(), s, w.wscale, (w.fp8 && !w.tr) ? 1 : 0);
 }
 int Net::pack_up(const ConvW& w, const float* params, char* base, hipStream_t s) {
-  return op_pack_up(dt(), geom(w), params + w.off, base + plan_.packed + w.packU * (long)esz(), s);
+  return op_pack_up(dt(), geom(w), params + w.off, base + plan_.packed + w.packU * (long)esz(), s, w.wscale, (w.fp8 && w.tr) ? 1 : 0);
 }
 int Net::run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
                   const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s,
                   const ConvW* w2, const void* x2) {
   SecondSrc q;
   if (w2) { q.x2 = x2; q.w2 = base + plan_.packed + w2->packU * (long)esz(); q.Cin2 = w2->D0; }
+  q.fp8 = (w.fp8 && !w.tr) ? 1 : 0;               // a Conv2d's forward
   return op_run_down(dt(), out_dt, geom(w), base + plan_.packed + w.packD * (long)esz(), N, L, Hl, Wl, S, Hs, Ws, pro_s, pro_b, relu,
                      stats, accumulate, s, q);
 }
@@ -206,6 +217,7 @@ int Net::run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws
                 const ConvW* w2, const void* x2) {
   SecondSrc q;
   if (w2) { q.x2 = x2; q.w2 = base + plan_.packed + w2->packU * (long)esz(); q.Cin2 = w2->D0; }
+  q.fp8 = (w.fp8 && w.tr) ? 1 : 0;                // a ConvTranspose2d's forward
   return op_run_up(dt(), geom(w), base + plan_.packed + w.packU * (long)esz(), N, S, Hs, Ws, L, Hl, Wl, pro_s, pro_b, relu, stats,
                    accumulate, s, q);
 }
@@ -260,7 +272,7 @@ int Net::side_wait_mark(int slot, hipStream_t s) {
 
 int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
                    const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s) {
-  return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_);
+  return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_, w.wscale);
 }
 
 bool Net::tail_fwd_fused() const {
@@ -284,8 +296,9 @@ int Net::sync_rows(char* base, const float* partials, int nparts, int width, hip
 }
 
 int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s,
-                  long part_off) {
+                  long part_off, float in_scale) {
   BnFinalizeArgs a;
+  a.in_scale = in_scale;
   a.partials = reinterpret_cast<const float*>(base + plan_.partials) + part_off; a.nparts = nparts; a.C = bn.C; a.count = count;
   if (sync_bn_on()) {      // statistics over the global batch (equal shards per rank)
     float* row = nullptr;
@@ -300,9 +313,9 @@ int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nb
   return launch_bn_finalize(a, s);
 }
 
-int Net::bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s) {
+int Net::bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s, float in_scale) {
   return launch_bn_eval_affine(params + bn.g_off, params + bn.b_off, bnbuf + bn.rm_off, bnbuf + bn.rv_off, 1e-5f, bn.C,
-                               bnf(bn, base, 2), bnf(bn, base, 3), s);
+                               bnf(bn, base, 2), bnf(bn, base, 3), s, in_scale);
 }
 
 BnBwdFinalizeArgs Net::bwd_finalize_args(const Bn& bn, const float* params, float* grads, char* base, const float* partials, int nparts, int ny,
@@ -481,15 +494,15 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
       hipStream_t ss = fork ? wgrad_stream(s) : s;
       np = run_down(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, dt(), ss);
       MM_TRY(np);
-      MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
+      MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats, B.cs.wscale) : bn_eval(B.bs, params, bnbuf, base, ss, B.cs.wscale));
     }
     np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
-    MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b1, params, bnbuf, base, s));
+    MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s, 0, B.c1.wscale) : bn_eval(B.b1, params, bnbuf, base, s, B.c1.wscale));
     np = run_down(B.c2, base, N, base + B.y1, B.Hout, B.Wout, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
                   stats, 0, dt(), s);
     MM_TRY(np);
-    MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
+    MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s, 0, B.c2.wscale) : bn_eval(B.b2, params, bnbuf, base, s, B.c2.wscale));
     if (fork) MM_TRY(side_join(s));
     // identity shortcut (model.py:40,52): the block input itself, i.e. a unit "BatchNorm" (scale 1, shift 0) of it
     MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), B.identity ? xin : base + B.ys,
@@ -678,7 +691,7 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   // stem ConvTranspose2d(z -> 128, k2) on the 1x1 latent (model.py:159-161,182)
   int np = run_up(dstem, base, N, base + P.enc_t, 1, 1, base + P.y0d, 2, 2, nullptr, nullptr, 0, stats, 0, s);
   MM_TRY(np);
-  MM_TRY(training ? bn_train(dbn0, params, bnbuf, nbt, base, np, (double)N * 4, s) : bn_eval(dbn0, params, bnbuf, base, s));
+  MM_TRY(training ? bn_train(dbn0, params, bnbuf, nbt, base, np, (double)N * 4, s, 0, dstem.wscale) : bn_eval(dbn0, params, bnbuf, base, s, dstem.wscale));
   const void* xin = base + P.y0d;
   const float* xs = bnf(dbn0, base, 2);
   const float* xb = bnf(dbn0, base, 3);
@@ -700,17 +713,17 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
       hipStream_t ss = fork ? wgrad_stream(s) : s;
       np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, ss);
       MM_TRY(np);
-      MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats) : bn_eval(B.bs, params, bnbuf, base, ss));
+      MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats, B.cs.wscale) : bn_eval(B.bs, params, bnbuf, base, ss, B.cs.wscale));
     }
     np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hin, B.Win, xs, xb, 1, stats, 0, dt(), s);
     MM_TRY(np);
-    MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, (double)N * B.Hin * B.Win, s) : bn_eval(B.b1, params, bnbuf, base, s));
+    MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, (double)N * B.Hin * B.Win, s, 0, B.c1.wscale) : bn_eval(B.b1, params, bnbuf, base, s, B.c1.wscale));
     if (B.identity)    // 3x3 Conv2d, shape preserving
       np = run_down(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, dt(), s);
     else
       np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
     MM_TRY(np);
-    MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s) : bn_eval(B.b2, params, bnbuf, base, s));
+    MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s, 0, B.c2.wscale) : bn_eval(B.b2, params, bnbuf, base, s, B.c2.wscale));
     if (fork) MM_TRY(side_join(s));
     if (i == nd - 1 && tail_fwd_fused()) break;     // the join of the last block happens inside the tail conv kernel
     MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), B.identity ? xin : base + B.ys,

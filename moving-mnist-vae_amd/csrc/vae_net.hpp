@@ -12,7 +12,7 @@
 
 namespace mmvae {
 
-struct NetCfg { int in_ch, z, out_ch, S, need_logvar, dtype, blocks; };   // blocks: residual blocks per stage (reference: 1)
+struct NetCfg { int in_ch, z, out_ch, S, need_logvar, dtype, blocks, fp8; };   // fp8: forward convs of the deep layers on the fp8 MFMA   // blocks: residual blocks per stage (reference: 1)
 
 enum EntryKind : int { EK_PARAM = 0, EK_BN_F32 = 1, EK_BN_I64 = 2 };
 struct Entry { std::string name; int ndim; int shape[4]; int kind; long offset; };
@@ -20,7 +20,10 @@ struct Entry { std::string name; int ndim; int shape[4]; int kind; long offset; 
 // A conv-like weight [D0][D1][k][k] relating a "small" tensor S [N,Hs,Ws,D0] and a "large" tensor L [N,Hl,Wl,D1],
 // Hs = floor((Hl + 2p - k)/s) + 1.  Conv2d: weight (out,in,k,k), forward = down(L->S).  ConvTranspose2d: weight
 // (in,out,k,k), forward = up(S->L).
-struct ConvW { long off; int D0, D1, k, s, p; long packD, packU; };
+// fp8 (BASELINE configs[4]): the conv's FORWARD runs on the fp8 MFMA (e4m3 weights x e4m3 activations, f32 accumulate) with
+// the static power-of-two weight scale wscale; its stored output is y' = wscale * y, which the BatchNorm behind it absorbs exactly
+// (BnFinalizeArgs::in_scale); the backward pass uses the bf16 kernels on wscale * w and scales the weight gradient by wscale.
+struct ConvW { long off; int D0, D1, k, s, p; long packD, packU; bool tr = false; /* ConvTranspose2d: forward = up */ bool fp8 = false; float wscale = 1.f; };
 struct Bn { long g_off, b_off, rm_off, rv_off; int nbt_idx; int C; long ws; /* float offset of this BN's 7*C scratch */ };
 
 struct Block {   // encoder BasicBlock or decoder DeconvBottleneck (both: main c1->c2, shortcut cs, join)
@@ -99,7 +102,7 @@ class Net {
   int side_wait_mark(int slot, hipStream_t s);  // s waits for mark `slot`
   int dt() const { return cfg.dtype; }
   size_t esz() const { return dtype_size(cfg.dtype); }
-  ConvW add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack);
+  ConvW add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack, bool transposed = false);
   Bn add_bn(const std::string& prefix, int C);
   void add_entry(const std::string& name, std::initializer_list<int> shape, int kind, long off);
 
@@ -137,8 +140,9 @@ class Net {
   bool sync_bn_on() const { return ar_fn_ != nullptr || comm_ != nullptr; }
   int join(hipStream_t s) { return side_join(s); }
  private:
-  int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0);
-  int bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s);
+  int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0,
+               float in_scale = 1.f);
+  int bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s, float in_scale = 1.f);
   float* bnf(const Bn& bn, char* base, int which) const;   // 0 mean 1 istd 2 scale 3 shift 4 A 5 B 6 C
   const float* ones(char* base) const { return reinterpret_cast<const float*>(base + plan_.cvec); }
   const float* zeros(char* base) const { return reinterpret_cast<const float*>(base + plan_.cvec) + 256; }

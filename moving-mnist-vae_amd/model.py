@@ -23,7 +23,7 @@ from torch import nn
 
 from ._lib import MmvaeError, check, lib, ptr
 
-_DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+_DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2}
 
 
 def _stream():
@@ -295,7 +295,7 @@ class VAE(nn.Module):
         dt = compute_dtype or os.environ.get("MMVAE_DTYPE", "bf16")
         if dt not in _DTYPES:
             raise ValueError(f"compute_dtype must be one of {sorted(_DTYPES)}")
-        self.compute_dtype = "f32" if _DTYPES[dt] == 0 else "bf16"
+        self.compute_dtype = {0: "f32", 1: "bf16", 2: "fp8"}[_DTYPES[dt]]
 
         L = lib()
         h = ctypes.c_void_p()
