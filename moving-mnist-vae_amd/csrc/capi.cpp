@@ -210,23 +210,29 @@ int mmvae_conv2d_fwd(int dt, int transposed, const void* x, const float* w, void
   const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
   const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
   // weight == NULL: `scratch` still holds the packed weights of an earlier call with the same geometry (pack once, run many)
+  SecondSrc q;
   if (!transposed) {
-    if (w) { int rc = op_pack_down(dt, g, w, scratch, S(st)); if (rc < 0) return rc; }
-    return op_run_down(dt, dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st));
+    q.wfrag = op_frag_down(dt, g, H, W);
+    if (w) { int rc = op_pack_down(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc; }
+    return op_run_down(dt, dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st), q);
   }
-  if (w) { int rc = op_pack_up(dt, g, w, scratch, S(st)); if (rc < 0) return rc; }
-  return op_run_up(dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st));
+  q.wfrag = op_frag_up(dt, g, Ho, Wo);
+  if (w) { int rc = op_pack_up(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc; }
+  return op_run_up(dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st), q);
 }
 int mmvae_conv2d_dgrad(int dt, int transposed, const void* dy, const float* w, void* dx, int N, int H, int W, int Cin, int Cout, int k,
                        int s, int p, void* scratch, void* st) {
   const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
   const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
+  SecondSrc q;
   if (!transposed) {
-    int rc = op_pack_up(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
-    return op_run_up(dt, g, scratch, N, dy, Ho, Wo, dx, H, W, nullptr, nullptr, 0, nullptr, 0, S(st));
+    q.wfrag = op_frag_up(dt, g, H, W);
+    int rc = op_pack_up(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc;
+    return op_run_up(dt, g, scratch, N, dy, Ho, Wo, dx, H, W, nullptr, nullptr, 0, nullptr, 0, S(st), q);
   }
-  int rc = op_pack_down(dt, g, w, scratch, S(st)); if (rc < 0) return rc;
-  return op_run_down(dt, dt, g, scratch, N, dy, Ho, Wo, dx, H, W, nullptr, nullptr, 0, nullptr, 0, S(st));
+  q.wfrag = op_frag_down(dt, g, Ho, Wo);
+  int rc = op_pack_down(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc;
+  return op_run_down(dt, dt, g, scratch, N, dy, Ho, Wo, dx, H, W, nullptr, nullptr, 0, nullptr, 0, S(st), q);
 }
 int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int k,
                        int s, int p, const float* ps, const float* pb, int relu, void* scratch, void* st) {

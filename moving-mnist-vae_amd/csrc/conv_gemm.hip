@@ -502,13 +502,109 @@ static int try_deep(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   return launch_deep_conv(dt, out_dt, b, gx, s);
 }
 
+// deep2_conv_kernel (conv_deep2.inc): weights from L2 straight into MFMA fragments, no barrier in the K loop.  MMVAE_DEEP2=0: off
+static bool deep2_enabled() {
+  static const int enabled = [] { const char* e = getenv("MMVAE_DEEP2"); return e ? atoi(e) : 1; }();
+  return enabled != 0 && !conv_force_v1();
+}
+// LDS bytes of a tile of npt*16 q-pixels (whole images)
+static size_t deep2_lds_for(int dt, int Cin, int Cout, int hw, int HiWi, int ntaps_all, int npt) {
+  DeepArgs b; memset(&b, 0, sizeof(b));
+  b.Cin = Cin; b.Hi = HiWi; b.Wi = 1; b.ipt = npt * 16 / hw; b.npt = npt; b.ntaps_all = ntaps_all; b.nw = Cout / 32 < 8 ? Cout / 32 : 8;
+  return deep2_conv_lds_bytes(b, dt);
+}
+bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, int ntaps_all) {
+  if (!deep2_enabled()) return false;
+  const int ES = dt == DT_F32 ? 4 : 2;
+  const int cpt = Cin * ES / 64;
+  if (Cin < 64 || (Cin * ES) % 64 != 0 || (cpt != (ES == 2 ? 2 : 4) && cpt != (ES == 2 ? 4 : 8) && cpt != (ES == 2 ? 8 : 16))) return false;   // Cin 64, 128, 256
+  if (Cout < 64 || Cout % 64 != 0 || (Cout > 256 && Cout % 256 != 0)) return false;
+  const int hw = Hq * Wq;
+  if (hw < 1 || hw > 128 || Hq > 255 || Wq > 255 || ntaps_all < 1 || ntaps_all > kMaxTaps) return false;
+  const int npt_min = hw > 64 ? 8 : hw > 32 ? 4 : 2;
+  return deep2_lds_for(dt, Cin, Cout, hw, Hi * Wi, ntaps_all, npt_min) <= 150 * 1024;
+}
+static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
+  static const int npt_env = [] { const char* e = getenv("MMVAE_DEEP2_NPT"); return e ? atoi(e) : 0; }();
+  if (a.x_planar || a.y_planes || a.fp8 || a.x2) return 0;
+  int Hq = 0, Wq = 0, ntaps_all = 0;
+  for (int p = 0; p < a.nphase; ++p) {
+    const Phase& ph = a.phases[p];
+    if (ph.ntaps <= 0) return 0;
+    Hq = ph.Hq > Hq ? ph.Hq : Hq; Wq = ph.Wq > Wq ? ph.Wq : Wq;
+    ntaps_all = ph.tap0 + ph.ntaps > ntaps_all ? ph.tap0 + ph.ntaps : ntaps_all;
+  }
+  if (!deep2_shape_ok(dt, a.Cin, a.Cout, Hq, Wq, a.Hi, a.Wi, ntaps_all)) return 0;
+  if ((long)a.N * a.Ho * a.Wo * a.Cout >= (1L << 32)) return 0;
+  const int ES = dt == DT_F32 ? 4 : 2, VE = 16 / ES;
+  const int cpt = a.Cin * ES / 64;
+  DeepArgs b; memset(&b, 0, sizeof(b));
+  b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
+  b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate; b.wfrag = a.wfrag;
+  b.N = a.N; b.Hi = a.Hi; b.Wi = a.Wi; b.Cin = a.Cin; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = a.SI; b.SO = a.SO;
+  b.nphase = a.nphase; b.Hq = Hq; b.Wq = Wq; b.ntaps_all = ntaps_all;
+  for (int p = 0; p < a.nphase; ++p) {
+    const Phase& ph = a.phases[p];
+    b.phases[p] = DeepPhase{ph.ph, ph.pw, ph.Hq, ph.Wq, ph.ntaps, ph.tap0, ph.w_off};
+  }
+  for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
+  for (b.cpt_log2 = 0; (1 << b.cpt_log2) < cpt; ++b.cpt_log2) {}
+  b.nw = a.Cout / 32 < 8 ? a.Cout / 32 : 8;
+  if ((64 * b.nw) % (a.Cin / VE) != 0) return 0;
+  const int gy = a.Cout / (32 * b.nw);
+  const int hw = Hq * Wq;
+  // the largest tile (fewest re-reads of the weight matrix) that fits 72 KB of LDS (two blocks per CU) and leaves no CU idle;
+  // else the largest that fits at all
+  int best = 0;
+  for (int pass = 0; pass < 2 && !best; ++pass)
+    for (int npt = 8; npt >= 2 && !best; npt >>= 1) {
+      if (npt_env && npt != npt_env && pass == 0) continue;
+      if (hw > npt * 16) break;
+      const size_t lds = deep2_lds_for(dt, a.Cin, a.Cout, hw, a.Hi * a.Wi, ntaps_all, npt);
+      int ipt = npt * 16 / hw; if (ipt > a.N) ipt = a.N;
+      const long ntiles = (a.N + ipt - 1) / ipt;
+      if (pass == 0) {
+        if (lds > 72 * 1024) continue;
+        if (!npt_env && npt > 2 && ntiles * gy * b.nw < 256 * 8 && (long)a.N * hw > 256 * 8 * (npt * 16 / 2) / (gy * b.nw)) continue;
+      } else if (lds > 150 * 1024) continue;
+      best = npt;
+    }
+  if (!best) return 0;
+  b.npt = best; b.ipt = best * 16 / hw;
+  if (b.ipt > a.N) b.ipt = a.N;
+  b.ntiles = (a.N + b.ipt - 1) / b.ipt;
+  int gx = b.ntiles < kGatherMaxGridX ? b.ntiles : kGatherMaxGridX;
+#ifdef MMVAE_DEEP2_TS
+  {
+    static long long* tsbuf = nullptr; static int tscount = 0;
+    if (!tsbuf && hipMalloc(&tsbuf, kGatherMaxGridX * 16 * 8) != hipSuccess) return MMVAE_ERR_HIP;
+    (void)hipMemsetAsync(tsbuf, 0, kGatherMaxGridX * 16 * 8, s);
+    b.ts = tsbuf;
+    const int rc = launch_deep2_conv(dt, out_dt, b, gx, s);
+    if (++tscount % 22 == 3) {
+      (void)hipStreamSynchronize(s);
+      static long long h[kGatherMaxGridX * 16];
+      (void)hipMemcpy(h, tsbuf, sizeof(h), hipMemcpyDeviceToHost);
+      fprintf(stderr, "DEEP2TS Cin=%d Cout=%d taps=%d Hi=%d ipt=%d npt=%d nw=%d ntiles=%d gx=%d lds=%zu frag=%d\n", b.Cin, b.Cout, b.ntaps_all, b.Hi, b.ipt, b.npt, b.nw, b.ntiles, gx, deep2_conv_lds_bytes(b, dt), b.wfrag);
+      for (int blk : {0, 1, gx / 2, gx - 1}) {
+        fprintf(stderr, "  blk %4d:", blk);
+        for (int i = 1; i < 16 && h[blk * 16 + i]; ++i) fprintf(stderr, " %7lld", h[blk * 16 + i] - h[blk * 16 + i - 1]);
+        fprintf(stderr, "\n");
+      }
+    }
+    return rc;
+  }
+#endif
+  return launch_deep2_conv(dt, out_dt, b, gx, s);
+}
+
 // the second source as its own accumulate launch (shapes the patch-tile kernel does not merge)
 static int launch_x2_separately(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   GatherArgs b; memset(&b, 0, sizeof(b));
   int Hq = 0, Wq = 0;
   for (int p = 0; p < a.nphase; ++p) if (a.phases[p].ph == a.x2_ph && a.phases[p].pw == a.x2_pw) { Hq = a.phases[p].Hq; Wq = a.phases[p].Wq; }
   if (Hq <= 0) { set_error("gather_gemm: the second source's phase (%d,%d) is not part of the launch", a.x2_ph, a.x2_pw); return MMVAE_ERR_ARG; }
-  b.x = a.x2; b.w = a.w2; b.y = a.y; b.accumulate = 1;
+  b.x = a.x2; b.w = a.w2; b.y = a.y; b.accumulate = 1; b.wfrag = a.wfrag2;
   b.N = a.N; b.Hi = Hq; b.Wi = Wq; b.Cin = a.Cin2; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = 1; b.SO = a.SO;
   b.nphase = 1; b.phases[0] = Phase{a.x2_ph, a.x2_pw, Hq, Wq, 1, 0, 0}; b.taps[0] = Tap{0, 0};
   return launch_gather_gemm(dt, out_dt, b, s);
@@ -525,10 +621,11 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
     return rc;
   }
   if (a.x2) {
+    // fragment-major weights are read by deep2_conv_kernel only, which takes one source: two launches then
     static const bool merge = [] { const char* e = getenv("MMVAE_X2_MERGE"); return !(e && e[0] == '0'); }();
-    int rc = (merge && !conv_force_v1()) ? try_patch(dt, out_dt, a, s) : 0;
+    int rc = (merge && !conv_force_v1() && !a.wfrag && !a.wfrag2) ? try_patch(dt, out_dt, a, s) : 0;
     if (rc != 0) return rc;
-    GatherArgs m = a; m.x2 = nullptr; m.w2 = nullptr; m.Cin2 = 0;
+    GatherArgs m = a; m.x2 = nullptr; m.w2 = nullptr; m.Cin2 = 0; m.wfrag2 = 0;
     rc = launch_gather_gemm(dt, out_dt, m, s);
     if (rc < 0) return rc;
     const int rc2 = launch_x2_separately(dt, out_dt, a, s);
@@ -550,9 +647,13 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   }
   if (ntap > kMaxTaps) { set_error("gather_gemm: %d taps > %d", ntap, kMaxTaps); return MMVAE_ERR_UNSUPPORTED; }
   if (max_tiles <= 0) return 1;
+  if (a.wfrag && conv_force_v1()) { set_error("gather_gemm: fragment-major weights with MMVAE_CONV_V1"); return MMVAE_ERR_UNSUPPORTED; }
   if (!conv_force_v1()) {
-    const int rcp = try_patch(dt, out_dt, a, s);
+    const int rcp = a.wfrag ? 0 : try_patch(dt, out_dt, a, s);
     if (rcp != 0) return rcp;
+    const int rcd2 = try_deep2(dt, out_dt, a, s);
+    if (rcd2 != 0) return rcd2;
+    if (a.wfrag) { set_error("gather_gemm: fragment-major weights (Cin=%d Cout=%d) need the deep2 kernel, which does not take this launch", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }
     const int rcd = try_deep(dt, out_dt, a, s);
     if (rcd != 0) return rcd;
   }
@@ -881,6 +982,16 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
 }
 
 // ============================================================================ weight packing
+// fragment-major position of element (col, kk) of a [cols][Ktot] matrix (PackArgs::frag)
+template <typename T>
+__device__ __forceinline__ long frag_index(int col, int kk, int Ktot) {
+  constexpr int VE = Elem<T>::kVec, CK = 4 * VE;     // elements per 16 bytes, per 64-byte chunk
+  const int chunk = kk / CK, in = kk - chunk * CK;
+  // column q of a wave's 32 is row 4*(q/8) + q%4 of its fragment (q/4)%2 (a lane's results are then 8 consecutive columns)
+  const int q = col & 31;
+  const int blk = 2 * (col >> 5) + ((q >> 2) & 1), r = 4 * (q >> 3) + (q & 3);
+  return (((long)blk * (Ktot / CK) + chunk) * 64 + (in / VE) * 16 + r) * VE + (in % VE);
+}
 template <typename T>
 __global__ void pack_kernel(PackArgs a) {
   const long total = (long)a.cols * a.ntaps * a.K;
@@ -891,12 +1002,12 @@ __global__ void pack_kernel(PackArgs a) {
     const int col = (int)(q / a.ntaps);
     const bool real = (a.cols_valid <= 0 || col < a.cols_valid) && (a.K_valid <= 0 || k < a.K_valid);
     const float v = real ? a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale : 0.f;
-    Elem<T>::store(reinterpret_cast<T*>(a.dst) + i, v);
+    Elem<T>::store(reinterpret_cast<T*>(a.dst) + (a.frag ? frag_index<T>(col, tp * a.K + k, a.ntaps * a.K) : i), v);
   }
 }
 
 struct PackJob {
-  const float* src; void* dst; int cols, K, ntaps, s_col, s_k, cols_valid, K_valid; float scale; unsigned char tap_off[27]; unsigned char fp8;
+  const float* src; void* dst; int cols, K, ntaps, s_col, s_k, cols_valid, K_valid; float scale; unsigned char tap_off[26]; unsigned char frag; unsigned char fp8;
 };
 __device__ __forceinline__ unsigned char f32_to_e4m3(float v) {
   v = fminf(fmaxf(v, -448.f), 448.f);
@@ -917,7 +1028,7 @@ __global__ void pack_multi_kernel(PackMulti m) {
     const bool real = (a.cols_valid <= 0 || col < a.cols_valid) && (a.K_valid <= 0 || k < a.K_valid);
     const float v = real ? a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale : 0.f;
     if (a.fp8) reinterpret_cast<unsigned char*>(a.dst)[i] = f32_to_e4m3(v);
-    else Elem<T>::store(reinterpret_cast<T*>(a.dst) + i, v);
+    else Elem<T>::store(reinterpret_cast<T*>(a.dst) + (a.frag ? frag_index<T>(col, tp * a.K + k, a.ntaps * a.K) : i), v);
   }
 }
 
@@ -946,10 +1057,11 @@ int launch_pack(int dt, const PackArgs& a, hipStream_t s) {
   const long total = (long)a.cols * a.ntaps * a.K;
   if (total <= 0) return MMVAE_OK;
   if (g_pack_batching) {
-    if (g_pack_n >= 256 || a.ntaps > 27) { set_error("pack batch overflow"); return MMVAE_ERR_ARG; }
+    if (g_pack_n >= 256 || a.ntaps > 26) { set_error("pack batch overflow"); return MMVAE_ERR_ARG; }
+    if (a.frag && a.fp8) { set_error("pack: fragment-major fp8 is not a layout any kernel reads"); return MMVAE_ERR_UNSUPPORTED; }
     PackJob& j = g_pack_jobs[g_pack_n++];
     j.src = a.src; j.dst = a.dst; j.cols = a.cols; j.K = a.K; j.ntaps = a.ntaps; j.s_col = a.s_col; j.s_k = a.s_k;
-    j.cols_valid = a.cols_valid; j.K_valid = a.K_valid; j.scale = a.scale; j.fp8 = (unsigned char)(a.fp8 ? 1 : 0);
+    j.cols_valid = a.cols_valid; j.K_valid = a.K_valid; j.scale = a.scale; j.fp8 = (unsigned char)(a.fp8 ? 1 : 0); j.frag = (unsigned char)(a.frag ? 1 : 0);
     for (int t = 0; t < a.ntaps; ++t) j.tap_off[t] = (unsigned char)a.tap_off[t];
     return MMVAE_OK;
   }

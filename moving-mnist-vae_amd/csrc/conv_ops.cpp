@@ -1,5 +1,6 @@
 #include "conv_ops.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace mmvae {
@@ -34,17 +35,17 @@ static int up_phases(int k, int s, int p, UpPhase* out) {
 }
 
 
-int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale, int fp8) {
+int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale, int fp8, int frag) {
   PackArgs a; std::memset(&a, 0, sizeof(a));
   const int kk = g.k * g.k;
   if (kk > kMaxTaps) { set_error("pack_down: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
   a.src = w; a.dst = dst;
-  a.cols = g.D0; a.K = g.D1; a.ntaps = kk; a.s_col = g.D1 * kk; a.s_k = kk; a.scale = scale; a.fp8 = fp8;
+  a.cols = g.D0; a.K = g.D1; a.ntaps = kk; a.s_col = g.D1 * kk; a.s_k = kk; a.scale = scale; a.fp8 = fp8; a.frag = frag;
   for (int t = 0; t < kk; ++t) a.tap_off[t] = t;
   return launch_pack(dt, a, s);
 }
 
-int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale, int fp8) {
+int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale, int fp8, int frag) {
   if (g.s > 2 || g.k * g.k > kMaxTaps) { set_error("pack_up: k=%d s=%d unsupported", g.k, g.s); return MMVAE_ERR_UNSUPPORTED; }
   UpPhase ph[4];
   const int np = up_phases(g.k, g.s, g.p, ph);
@@ -55,7 +56,7 @@ int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t
     if (ph[i].ntaps == 0) continue;
     PackArgs a; std::memset(&a, 0, sizeof(a));
     a.src = w; a.dst = static_cast<char*>(dst) + off * e;
-    a.cols = g.D1; a.K = g.D0; a.ntaps = ph[i].ntaps; a.s_col = kk; a.s_k = g.D1 * kk; a.scale = scale; a.fp8 = fp8;
+    a.cols = g.D1; a.K = g.D0; a.ntaps = ph[i].ntaps; a.s_col = kk; a.s_k = g.D1 * kk; a.scale = scale; a.fp8 = fp8; a.frag = frag;
     for (int t = 0; t < ph[i].ntaps; ++t) a.tap_off[t] = ph[i].kh[t] * g.k + ph[i].kw[t];
     MM_TRY(launch_pack(dt, a, s));
     off += (long)g.D1 * ph[i].ntaps * g.D0;
@@ -63,12 +64,32 @@ int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t
   return MMVAE_OK;
 }
 
+// MMVAE_DEEP2_FRAG=0: keep the row-major [cout][tap][cin] packing for deep2_conv_kernel too (A/B of the layout; both are read correctly)
+static bool frag_enabled() {
+  static const bool v = [] { const char* e = getenv("MMVAE_DEEP2_FRAG"); return !(e && e[0] == '0'); }();
+  return v;
+}
+int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl) {
+  if (!frag_enabled()) return 0;
+  const int Hs = conv_down_size(Hl, g.k, g.s, g.p), Ws = conv_down_size(Wl, g.k, g.s, g.p);
+  return deep2_shape_ok(dt, g.D1, g.D0, Hs, Ws, Hl, Wl, g.k * g.k) ? 1 : 0;
+}
+int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases) {
+  if (!frag_enabled() || g.s > 2 || g.k * g.k > kMaxTaps) return 0;
+  const int Hs = conv_down_size(Hl, g.k, g.s, g.p), Ws = conv_down_size(Wl, g.k, g.s, g.p);
+  UpPhase ph[4];
+  const int np = up_phases(g.k, g.s, g.p, ph);
+  int ntaps = 0;
+  for (int i = 0; i < np; ++i) { if (ph[i].ntaps == 0 && !allow_empty_phases) return 0; ntaps += ph[i].ntaps; }
+  return deep2_shape_ok(dt, g.D0, g.D1, (Hl + g.s - 1) / g.s, (Wl + g.s - 1) / g.s, Hs, Ws, ntaps) ? 1 : 0;
+}
+
 int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
                 const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s, const SecondSrc& x2) {
   GatherArgs a; std::memset(&a, 0, sizeof(a));
   if (g.k * g.k > kMaxTaps) { set_error("run_down: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
   if (x2.x2) { a.x2 = x2.x2; a.w2 = x2.w2; a.Cin2 = x2.Cin2; a.x2_ph = 0; a.x2_pw = 0; }
-  a.fp8 = x2.fp8;
+  a.fp8 = x2.fp8; a.wfrag = x2.wfrag; a.wfrag2 = x2.wfrag2;
   a.x = L; a.w = packed; a.y = S;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hl; a.Wi = Wl; a.Cin = g.D1; a.Ho = Hs; a.Wo = Ws; a.Cout = g.D0; a.SI = g.s; a.SO = 1;
@@ -84,7 +105,7 @@ int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* 
   if (g.s > 2 || g.k * g.k > kMaxTaps) { set_error("run_up: k=%d s=%d unsupported", g.k, g.s); return MMVAE_ERR_UNSUPPORTED; }
   GatherArgs a; std::memset(&a, 0, sizeof(a));
   if (x2.x2) { a.x2 = x2.x2; a.w2 = x2.w2; a.Cin2 = x2.Cin2; a.x2_ph = 0; a.x2_pw = 0; }
-  a.fp8 = x2.fp8;
+  a.fp8 = x2.fp8; a.wfrag = x2.wfrag; a.wfrag2 = x2.wfrag2;
   a.x = S; a.w = packed; a.y = L;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hs; a.Wi = Ws; a.Cin = g.D0; a.Ho = Hl; a.Wo = Wl; a.Cout = g.D1; a.SI = 1; a.SO = g.s;

@@ -13,13 +13,19 @@ struct ConvGeom { int D0, D1, k, s, p; };
 inline int conv_down_size(int H, int k, int s, int p) { return (H + 2 * p - k) / s + 1; }
 // packed element counts (both equal numel(weight)); 16-byte alignment is the caller's job
 // scale multiplies the weights (fp8 layers: the static per-layer scale); fp8 = 1 writes e4m3 bytes (batched packing only)
-int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0);
-int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0);
+// frag = 1: fragment-major order (PackArgs::frag) -- what deep2_conv_kernel reads; op_frag_down / op_frag_up say whether the run_down /
+// run_up launch of this geometry (large-side map Hl x Wl) goes to that kernel, i.e. whether to pack and run with the flag set.
+int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0, int frag = 0);
+int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0, int frag = 0);
+int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl);
+// allow_empty_phases: the launch accumulates (or is a second source), so stride phases without a tap are skipped, not zero-filled
+int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases = 0);
 // x2 / w2 / Cin2 (optional): a second tensor on the q grid (= S for run_down, = the S-resolution grid for run_up) whose 1x1
 // convolution with the packed [Cout][Cin2] matrix w2 is added into the result (phase (0,0) of run_up) in the same kernel.
 struct SecondSrc {
   const void* x2 = nullptr; const void* w2 = nullptr; int Cin2 = 0;
   int fp8 = 0;             // the forward conv runs on the fp8 MFMA (e4m3 packed weights)
+  int wfrag = 0, wfrag2 = 0;   // packed (w2) is fragment-major
 };
 int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
                 const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, hipStream_t s, const SecondSrc& x2 = SecondSrc());

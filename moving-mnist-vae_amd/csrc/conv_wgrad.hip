@@ -150,4 +150,19 @@ int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t 
   return launch_deep_conv_bf16(a, gx, s);
 }
 
+int launch_deep2_conv_f32(const DeepArgs& a, int gx, hipStream_t s);
+int launch_deep2_conv_bf16(const DeepArgs& a, int gx, hipStream_t s);
+int launch_deep2_conv_bf16_f32(const DeepArgs& a, int gx, hipStream_t s);
+
+size_t deep2_conv_lds_bytes(const DeepArgs& a, int dt) {
+  const size_t pitch = (size_t)a.Cin * dtype_size(dt) + 32;
+  return (size_t)(a.ipt * a.Hi * a.Wi + 1) * pitch + (size_t)a.npt * 16 * 4 + (size_t)a.nw * 64 * 4 + (size_t)a.ntaps_all * a.npt * 16 * 2;
+}
+
+int launch_deep2_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s) {
+  if (dt == DT_F32) return launch_deep2_conv_f32(a, gx, s);
+  if (out_dt == DT_F32) return launch_deep2_conv_bf16_f32(a, gx, s);
+  return launch_deep2_conv_bf16(a, gx, s);
+}
+
 }  // namespace mmvae

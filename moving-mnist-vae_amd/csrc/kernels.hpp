@@ -37,7 +37,11 @@ struct GatherArgs {
   // (3x3 / 4x4 main path + 1x1 shortcut) into one kernel: no read-modify-write of the sum.
   const void* x2; const void* w2; int Cin2, x2_ph, x2_pw;
   int fp8;                 // 1: w holds e4m3 bytes (same [cout][tap][cin] order); only the deep-layer kernel takes it (else an error)
+  int wfrag, wfrag2;       // 1: w (w2) is packed fragment-major (PackArgs::frag); only deep2_conv_kernel reads it (else an error)
 };
+// Shapes deep2_conv_kernel takes (conv_deep2.inc): the layers whose weights are packed fragment-major.  q grid Hq x Wq per phase
+// and image, input map Hi x Wi, ntaps over all phases.
+bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, int ntaps_all);
 // out_dt: dtype of y (may be DT_F32 while x/w are bf16).  Returns the number of stats partial rows (>0) or an error (<0).
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s);
 constexpr int kGatherMaxGridX = 1024;
@@ -141,9 +145,14 @@ struct DeepArgs {
   int ipt, ntiles;             // whole images per tile, tiles
   int ct16, npt;               // cout tile / 16 (4 or 8), 16-pixel column tiles per wave
   int fp8;                     // w is e4m3 bytes, activations are quantised in LDS: v_mfma_f32_16x16x32_fp8_fp8 (forward convs, bf16 storage)
+  int nw, cpt_log2;            // deep2_conv_kernel: waves per block (32 couts each), log2(64-byte chunks per tap of a weight row)
+  long long* ts;               // developer builds only (MMVAE_DEEP2_TS): per-block cycle stamps
+  int wfrag;                   // weights are fragment-major (PackArgs::frag)
 };
 size_t deep_conv_lds_bytes(const DeepArgs& a, int dt);
 int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
+size_t deep2_conv_lds_bytes(const DeepArgs& a, int dt);
+int launch_deep2_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);  // conv_deep2.inc; returns stats rows (= gx) or <0
 bool conv_force_v1();
 int conv_xcd_walk();      // MMVAE_XCD (default 1): XCD-aware tile order in the persistent patch-tile kernels   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 
@@ -153,6 +162,10 @@ struct PackArgs {
   const float* src; void* dst; int cols, K, ntaps; int s_col, s_k; int tap_off[kMaxTaps]; float scale;
   int cols_valid, K_valid;   // >0: columns / k beyond these are written as zero (channel padding), source not read
   int fp8;                   // 1: dst receives OCP e4m3 bytes (one per element) instead of T
+  // 1: fragment-major order for deep2_conv_kernel: the [cols][ntaps*K] matrix is cut into 16-column x 64-byte blocks, each stored as the
+  // 1 KB one wave loads as an MFMA A fragment (lane = 16*g + r holds 16 bytes: column 16*blk + r, bytes 16*g .. of the block's chunk):
+  // dst[((blk * nchunks + chunk) * 64 + 16*g + r) * VE + e]
+  int frag;
 };
 int launch_pack(int dt, const PackArgs& a, hipStream_t s);
 // Batched packing: between pack_batch_begin() and pack_batch_flush() every launch_pack() call is only recorded;

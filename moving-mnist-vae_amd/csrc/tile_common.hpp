@@ -19,6 +19,54 @@ template <typename T> __device__ __forceinline__ f32x4 mma_vec(const Vec16& a, c
 template <> __device__ __forceinline__ f32x4 mma_vec<bf16_t>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_bf16(a, b, c); }
 template <> __device__ __forceinline__ f32x4 mma_vec<float>(const Vec16& a, const Vec16& b, f32x4 c) { return mma_f32v(a, b, c); }
 
+// 4 consecutive output channels of one pixel (an MFMA D-fragment column), optionally accumulated onto what is stored
+template <typename TO> __device__ __forceinline__ void dstore4(TO* p, const float* v, bool acc);
+template <> __device__ __forceinline__ void dstore4<float>(float* p, const float* v, bool acc) {
+  float4 o = make_float4(v[0], v[1], v[2], v[3]);
+  if (acc) { const float4 e = *reinterpret_cast<const float4*>(p); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+  *reinterpret_cast<float4*>(p) = o;
+}
+template <> __device__ __forceinline__ void dstore4<bf16_t>(bf16_t* p, const float* v, bool acc) {
+  float f[4] = {v[0], v[1], v[2], v[3]};
+  if (acc) {
+    const uint2 e = *reinterpret_cast<const uint2*>(p);
+    f[0] += __uint_as_float(e.x << 16); f[1] += __uint_as_float(e.x & 0xffff0000u);
+    f[2] += __uint_as_float(e.y << 16); f[3] += __uint_as_float(e.y & 0xffff0000u);
+  }
+  uint2 o;
+  o.x = pack2_bf16(f[0], f[1]);
+  o.y = pack2_bf16(f[2], f[3]);
+  *reinterpret_cast<uint2*>(p) = o;
+}
+
+// 8 consecutive output channels of one pixel
+template <typename TO> __device__ __forceinline__ void dstore8(TO* p, const float* v, bool acc);
+template <> __device__ __forceinline__ void dstore8<float>(float* p, const float* v, bool acc) {
+  dstore4<float>(p, v, acc);
+  dstore4<float>(p + 4, v + 4, acc);
+}
+template <> __device__ __forceinline__ void dstore8<bf16_t>(bf16_t* p, const float* v, bool acc) {
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = v[j];
+  if (acc) {
+    const uint4 e = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] += __uint_as_float(w[j] << 16); f[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u); }
+  }
+  uint4 o;
+  o.x = pack2_bf16(f[0], f[1]); o.y = pack2_bf16(f[2], f[3]); o.z = pack2_bf16(f[4], f[5]); o.w = pack2_bf16(f[6], f[7]);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15); every lane receives it
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  return v;
+}
 // pixel-major MFMA fragments out of a natural-layout [pixel][channel] LDS image (weight-gradient style reductions over pixels)
 template <typename T> struct FragOps;
 template <> struct FragOps<bf16_t> {

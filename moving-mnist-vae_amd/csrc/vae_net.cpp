@@ -79,6 +79,7 @@ Net::Net(const NetCfg& c) : cfg(c) {
         B.cs = add_conv(p + "downsample.0.weight", planes[i], inpl, 1, 2, 0, true);  // conv1x1 stride 2 (:135-138)
         B.bs = add_bn(p + "downsample.1", planes[i]);
       }
+      B.c1.Hl = B.Hin; B.c2.Hl = B.Hout; B.cs.Hl = B.Hin;
       inpl = planes[i]; H = B.Hout;
       enc.push_back(B);
     }
@@ -96,6 +97,7 @@ Net::Net(const NetCfg& c) : cfg(c) {
   // ---- decoder (model.py:154-179)
   dec_param_off = n_params;
   dstem = add_conv("decoder.conv1.weight", c.z, 128, 2, 2, 0, true, true);   // k2 s1 p0 on a 1x1 input == k2 s2 p0
+  dstem.Hl = 2;
   dbn0 = add_bn("decoder.bn1", 128);
   nup = S > 32 ? 5 : 4;                                               // :169
   const int ups[5] = {128, 64, 32, 16, 16};
@@ -114,6 +116,7 @@ Net::Net(const NetCfg& c) : cfg(c) {
         B.b1 = add_bn(p + "bn1", cin);
         B.c2 = add_conv(p + "conv2.weight", cin, cin, 3, 1, 1, true);           // Conv2d (out,in,3,3): the shape-preserving main path
         B.b2 = add_bn(p + "bn2", cin);
+        B.c1.Hl = H; B.c2.Hl = H;
       } else {
         B.Cin = cin; B.C = ups[i]; B.Hin = B.Win = H; B.Hmid = B.Wmid = H; B.Hout = B.Wout = 2 * H;
         B.c1 = add_conv(p + "conv1.weight", ups[i], cin, 1, 1, 0, true);        // 1x1 (:60)
@@ -122,6 +125,7 @@ Net::Net(const NetCfg& c) : cfg(c) {
         B.b2 = add_bn(p + "bn2", ups[i]);
         B.cs = add_conv(p + "upsample.0.weight", cin, ups[i], 4, 2, 1, true, true);    // ConvT k4 s2 p1 (:198-201)
         B.bs = add_bn(p + "upsample.1", ups[i]);
+        B.c1.Hl = H; B.c2.Hl = 2 * H; B.cs.Hl = 2 * H;
         cin = ups[i]; H = 2 * H;
       }
       dec.push_back(B);
@@ -197,11 +201,17 @@ static inline ConvGeom geom(const ConvW& w) { return ConvGeom{w.D0, w.D1, w.k, w
 // fwd = 1: this pack feeds the conv's FORWARD direction (an fp8 layer then gets e4m3 bytes); every pack of an fp8 layer is scaled
 // the pack that feeds a conv's FORWARD direction (down for Conv2d, up for ConvTranspose2d) is e4m3 bytes on an fp8 layer; every pack
 // of an fp8 layer carries its weight scale
+// The up form of a 1x1 stride-2 shortcut has stride phases without a tap: in this net it only ever accumulates into (or rides along
+// with) the main path's data gradient, so those phases are skipped.
+int Net::frag_down(const ConvW& w) const { return (w.Hl > 0 && !(w.fp8 && !w.tr)) ? op_frag_down(dt(), geom(w), w.Hl, w.Hl) : 0; }
+int Net::frag_up(const ConvW& w) const { return (w.Hl > 0 && !(w.fp8 && w.tr)) ? op_frag_up(dt(), geom(w), w.Hl, w.Hl, 1) : 0; }
 int Net::pack_down(const ConvW& w, const float* params, char* base, hipStream_t s) {
-  return op_pack_down(dt(), geom(w), params + w.off, base + plan_.packed + w.packD * (long)esz(), s, w.wscale, (w.fp8 && !w.tr) ? 1 : 0);
+  return op_pack_down(dt(), geom(w), params + w.off, base + plan_.packed + w.packD * (long)esz(), s, w.wscale, (w.fp8 && !w.tr) ? 1 : 0,
+                      frag_down(w));
 }
 int Net::pack_up(const ConvW& w, const float* params, char* base, hipStream_t s) {
-  return op_pack_up(dt(), geom(w), params + w.off, base + plan_.packed + w.packU * (long)esz(), s, w.wscale, (w.fp8 && w.tr) ? 1 : 0);
+  return op_pack_up(dt(), geom(w), params + w.off, base + plan_.packed + w.packU * (long)esz(), s, w.wscale, (w.fp8 && w.tr) ? 1 : 0,
+                    frag_up(w));
 }
 int Net::run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,
                   const float* pro_s, const float* pro_b, int relu, float* stats, int accumulate, int out_dt, hipStream_t s,
@@ -209,6 +219,7 @@ int Net::run_down(const ConvW& w, char* base, int N, const void* L, int Hl, int 
   SecondSrc q;
   if (w2) { q.x2 = x2; q.w2 = base + plan_.packed + w2->packU * (long)esz(); q.Cin2 = w2->D0; }
   q.fp8 = (w.fp8 && !w.tr) ? 1 : 0;               // a Conv2d's forward
+  q.wfrag = frag_down(w); q.wfrag2 = w2 ? frag_up(*w2) : 0;
   return op_run_down(dt(), out_dt, geom(w), base + plan_.packed + w.packD * (long)esz(), N, L, Hl, Wl, S, Hs, Ws, pro_s, pro_b, relu,
                      stats, accumulate, s, q);
 }
@@ -218,6 +229,7 @@ int Net::run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws
   SecondSrc q;
   if (w2) { q.x2 = x2; q.w2 = base + plan_.packed + w2->packU * (long)esz(); q.Cin2 = w2->D0; }
   q.fp8 = (w.fp8 && w.tr) ? 1 : 0;                // a ConvTranspose2d's forward
+  q.wfrag = frag_up(w); q.wfrag2 = w2 ? frag_up(*w2) : 0;
   return op_run_up(dt(), geom(w), base + plan_.packed + w.packU * (long)esz(), N, S, Hs, Ws, L, Hl, Wl, pro_s, pro_b, relu, stats,
                    accumulate, s, q);
 }

@@ -23,7 +23,7 @@ struct Entry { std::string name; int ndim; int shape[4]; int kind; long offset; 
 // fp8 (BASELINE configs[4]): the conv's FORWARD runs on the fp8 MFMA (e4m3 weights x e4m3 activations, f32 accumulate) with
 // the static power-of-two weight scale wscale; its stored output is y' = wscale * y, which the BatchNorm behind it absorbs exactly
 // (BnFinalizeArgs::in_scale); the backward pass uses the bf16 kernels on wscale * w and scales the weight gradient by wscale.
-struct ConvW { long off; int D0, D1, k, s, p; long packD, packU; bool tr = false; /* ConvTranspose2d: forward = up */ bool fp8 = false; float wscale = 1.f; };
+struct ConvW { long off; int D0, D1, k, s, p; long packD, packU; int Hl = 0; /* large-side map (square) */ bool tr = false; /* ConvTranspose2d: forward = up */ bool fp8 = false; float wscale = 1.f; };
 struct Bn { long g_off, b_off, rm_off, rv_off; int nbt_idx; int C; long ws; /* float offset of this BN's 7*C scratch */ };
 
 struct Block {   // encoder BasicBlock or decoder DeconvBottleneck (both: main c1->c2, shortcut cs, join)
@@ -110,6 +110,9 @@ class Net {
   int packs_enc_bwd(const float* params, char* base, hipStream_t s);
   int packs_dec_fwd(const float* params, char* base, hipStream_t s);
   int packs_dec_bwd(const float* params, char* base, bool need_denc, hipStream_t s);
+  // fragment-major packing (deep2_conv_kernel) of the down / up form of a conv at its place in the net
+  int frag_down(const ConvW& w) const;
+  int frag_up(const ConvW& w) const;
   int pack_down(const ConvW& w, const float* params, char* base, hipStream_t s);
   int pack_up(const ConvW& w, const float* params, char* base, hipStream_t s);
   // w2 / x2 (optional): the 1x1 conv whose "up" form over x2 (a tensor on the small-side grid) is added in the same kernel

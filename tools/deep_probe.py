@@ -1,0 +1,79 @@
+"""Developer tool (GPU box): every channel-heavy (Cin, Cout >= 64) convolution of the config-2 network timed in isolation through the
+C ABI (forward and dgrad), with its FLOP count and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak.
+usage: python tools/deep_probe.py [N=5120] [reps=20]"""
+import ctypes
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.getcwd())
+L = importlib.import_module("moving-mnist-vae_amd._lib")
+
+# name, transposed, Cin, Cout, k, s, p, H (input side of the forward op)
+LAYERS = [
+    ("enc.layer2.conv2", 0, 64, 64, 3, 1, 1, 8),
+    ("enc.layer3.conv1", 0, 64, 128, 3, 2, 1, 8),
+    ("enc.layer3.down", 0, 64, 128, 1, 2, 0, 8),
+    ("enc.layer3.conv2", 0, 128, 128, 3, 1, 1, 4),
+    ("enc.layer4.conv1", 0, 128, 256, 3, 2, 1, 4),
+    ("enc.layer4.down", 0, 128, 256, 1, 2, 0, 4),
+    ("enc.layer4.conv2", 0, 256, 256, 3, 1, 1, 2),
+    ("dec.conv1", 1, 128, 128, 2, 2, 0, 1),
+    ("dec.up1.conv1", 0, 128, 128, 1, 1, 0, 2),
+    ("dec.up1.conv2", 1, 128, 128, 4, 2, 1, 2),
+    ("dec.up2.conv1", 0, 128, 64, 1, 1, 0, 4),
+    ("dec.up2.conv2", 1, 64, 64, 4, 2, 1, 4),
+    ("dec.up2.upsample", 1, 128, 64, 4, 2, 1, 4),
+]
+
+
+def main(N=5120, reps=20):
+    lib = L.lib()
+    dev = torch.device("cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    print(f"{'layer':20s} {'op':6s} {'us':>8s} {'GFLOP':>7s} {'TFLOP/s':>8s} {'%peak':>6s} {'MB':>7s} {'TB/s':>6s}")
+    tot = 0.0
+    for name, tr, Cin, Cout, k, st, p, H in LAYERS:
+        Ho = (H - 1) * st - 2 * p + k if tr else (H + 2 * p - k) // st + 1
+        w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device=dev) * 0.05
+        x = torch.randn(N, H, H, Cin, device=dev).to(torch.bfloat16)
+        y = torch.empty(N, Ho, Ho, Cout, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty_like(x)
+        scratch = torch.empty(4 * w.numel() + 1024, device=dev, dtype=torch.uint8)
+        sc = torch.rand(Cin, device=dev) + 0.5
+        sh = torch.randn(Cin, device=dev) * 0.1
+        stats = torch.empty(4096 * 2 * Cout, device=dev)
+        flop = 2.0 * N * (H * H if tr else Ho * Ho) * Cin * Cout * k * k
+        mb = (x.numel() + y.numel()) * 2 / 1e6
+        P = lambda v: v
+
+        def fwd(pack):
+            rc = lib.mmvae_conv2d_fwd(1, tr, P(x.data_ptr()), P(w.data_ptr()) if pack else None, P(y.data_ptr()), N, H, H, Cin, Cout, k, st,
+                                      p, P(sc.data_ptr()), P(sh.data_ptr()), 1, P(stats.data_ptr()), P(scratch.data_ptr()), P(s))
+            L.check(rc, name)
+
+        def dgrad(pack):
+            rc = lib.mmvae_conv2d_dgrad(1, tr, P(y.data_ptr()), P(w.data_ptr()), P(dx.data_ptr()), N, H, H, Cin, Cout, k, st, p,
+                                        P(scratch.data_ptr()), P(s))
+            L.check(rc, name)
+
+        for op, fn in (("fwd", fwd),):
+            fn(True)
+            fn(False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn(False)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            tot += us
+            print(f"{name:20s} {op:6s} {us:8.1f} {flop / 1e9:7.2f} {flop / us / 1e6:8.1f} {flop / us / 1e6 / 2500 * 100:6.1f} {mb:7.1f} {mb / us:6.2f}")
+    print(f"sum {tot:.1f} us")
+
+
+if __name__ == "__main__":
+    main(*[int(a) for a in sys.argv[1:]])
