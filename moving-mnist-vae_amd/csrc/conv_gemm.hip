@@ -549,11 +549,13 @@ static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   }
   for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
   for (b.cpt_log2 = 0; (1 << b.cpt_log2) < cpt; ++b.cpt_log2) {}
+  static const int nw_env = [] { const char* e = getenv("MMVAE_DEEP2_NW"); return e ? atoi(e) : 0; }();
   b.nw = a.Cout / 32 < 8 ? a.Cout / 32 : 8;
+  if (nw_env && nw_env <= b.nw && (a.Cout / 32) % nw_env == 0) b.nw = nw_env;
   if ((64 * b.nw) % (a.Cin / VE) != 0) return 0;
   const int gy = a.Cout / (32 * b.nw);
   const int hw = Hq * Wq;
-  // the largest tile (fewest re-reads of the weight matrix) that fits 72 KB of LDS (two blocks per CU) and leaves no CU idle;
+  // the largest tile (fewest re-reads of the weight matrix) that fits 80 KB of LDS (two blocks per CU) and leaves no SIMD idle;
   // else the largest that fits at all
   int best = 0;
   for (int pass = 0; pass < 2 && !best; ++pass)
@@ -564,8 +566,9 @@ static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
       int ipt = npt * 16 / hw; if (ipt > a.N) ipt = a.N;
       const long ntiles = (a.N + ipt - 1) / ipt;
       if (pass == 0) {
-        if (lds > 72 * 1024) continue;
-        if (!npt_env && npt > 2 && ntiles * gy * b.nw < 256 * 8 && (long)a.N * hw > 256 * 8 * (npt * 16 / 2) / (gy * b.nw)) continue;
+        if (lds > 80 * 1024) continue;
+        // measured (tools/deep_sweep.sh): below one wave per SIMD a smaller tile wins, above it the larger tile's halved weight traffic does
+        if (!npt_env && npt > 2 && ntiles * gy * b.nw < 256 * 4) continue;
       } else if (lds > 150 * 1024) continue;
       best = npt;
     }
