@@ -1,0 +1,270 @@
+// wgrad_stream_kernel: weight gradient of the stride-2 k4 layers on the big, thin feature maps (ConvTranspose2d 16/32 -> 16
+// channels, 32x32 -> 64x64: decoder.uplayer5.conv2 / .upsample, 839 MB of operands each at N = 5120) as a barrier-free stream.
+//
+//   dW[a][b][kh][kw] = sum_{n,h,w} P[n,h,w,a] * G[n, S*h + kh - PAD, S*w + kw - PAD, b]        (P: small grid, G: large grid)
+//
+// wgrad2_kernel (conv_wgrad.inc) stages a 128-pixel P tile and its G patch per block behind two barriers and moves these layers
+// at 2.0-2.9 TB/s.  Here every WAVE walks strips of P rows on its own: a ring of G rows and the current P row live in
+// wave-private LDS (no block barrier anywhere in the loop), every G row is loaded from memory exactly once per strip, the
+// next step's rows are in flight in registers while the current step multiplies, and all KS*KS tap accumulators of the
+// (Ca x Cb) tile stay in registers.  One step = 32 P pixels (one row) = one MFMA K-step: the A fragment (P^T) and the 16 B
+// fragments (G rows S*h+kh-PAD, columns S*w+kw-PAD) come out of the natural [pixel][channel] LDS images through
+// ds_read_b64_tr_b16.  Out-of-range rows and the two border columns are zeros in LDS.  At the end the block's waves add their
+// accumulators in LDS and store ONE partial image [tap][a][b] per block (summed by wgrad_reduce_kernel: no atomics, fixed order).
+#include <hip/hip_runtime.h>
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.hpp"
+#include "tile_common.hpp"
+
+namespace mmvae {
+
+struct WStreamArgs {
+  const void* P; const void* G; float* part;
+  const float* proP_scale; const float* proP_shift; int proP_relu;
+  const float* proG_scale; const float* proG_shift; int proG_relu;
+  int N, Hp, Hg, Wg;
+  int HS;                    // P rows per strip (divides Hp)
+  int nunits;                // N * Hp / HS
+};
+
+// KS x KS taps, stride S, padding PAD; WP = P row width (32: one row per MFMA K-step); CA16, CB16: channel tiles of P and G
+template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G>
+__global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
+  static_assert(WP == 32, "one P row per K-step");
+  constexpr int CAB = CA16 * 32, CBB = CB16 * 32;          // bytes per P / G pixel
+  constexpr int WL = S * (WP - 1) + KS;                    // G columns a P row reaches: -PAD .. S*(WP-1)+KS-1-PAD
+  constexpr int ROWB = WL * CBB;                           // bytes per LDS G row
+  constexpr int NSLOT = KS + S;                            // ring: the KS rows being multiplied + the S rows arriving
+  constexpr int PB = WP * CAB;                             // bytes of a P row
+  constexpr int WAVE_LDS = NSLOT * ROWB + PB;
+  constexpr int NT = KS * KS;
+  constexpr int WSIZE = NT * CA16 * 16 * CB16 * 16;        // floats of a partial image
+  static_assert(4 * WAVE_LDS >= WSIZE * 4, "the flush image aliases the rings");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
+  char* ring = smem + wv * WAVE_LDS;
+  char* prow = ring + NSLOT * ROWB;
+  constexpr int Wg = S * WP;                               // G row width (the launcher checks it)
+  constexpr int grow_bytes = Wg * CBB;                     // bytes of a G row in memory
+  constexpr int GV = (S * grow_bytes + 1023) / 1024;       // 16-byte vectors per lane for the S rows of a step
+  constexpr int PV = PB / 1024;                            // ... for the P row
+  static_assert(PB % 1024 == 0, "P row = whole wave loads");
+
+  // ---- border columns are zero for the whole kernel: columns [0, PAD) and [PAD + Wg, WL) of every slot
+  for (int s = 0; s < NSLOT; ++s) {
+    for (int i = lane; i < (PAD * CBB) / 16; i += 64) reinterpret_cast<Vec16*>(ring + s * ROWB)[i] = Vec16{{0, 0, 0, 0}};
+    for (int i = lane; i < ((WL - PAD) * CBB - grow_bytes) / 16; i += 64)
+      reinterpret_cast<Vec16*>(ring + s * ROWB + PAD * CBB + grow_bytes)[i] = Vec16{{0, 0, 0, 0}};
+  }
+  // ---- prologue coefficients of the channels this lane stages (8 consecutive channels per 16-byte vector)
+  float psc[8], psh[8], gsc[8], gsh[8];
+  if (PRO_P) {
+    const int c = (lane % (CAB / 16)) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { psc[j] = a.proP_scale[c + j]; psh[j] = a.proP_shift[c + j]; }
+  }
+  if (PRO_G) {
+    const int c = (lane % (CBB / 16)) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gsc[j] = a.proG_scale[c + j]; gsh[j] = a.proG_shift[c + j]; }
+  }
+  const float p_lo = a.proP_relu ? 0.f : -__builtin_inff(), g_lo = a.proG_relu ? 0.f : -__builtin_inff();
+  // ---- fragment offsets (tile-invariant): k-slice gq = P pixels 8gq .. 8gq+7, two 4-pixel blocks; lane i = r supplies the
+  // address of pixel (i >> 2) of the block, channel quad (i & 3)
+  int offA[2], offB[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const int w = 8 * gq + 4 * blk + (r >> 2);
+    offA[blk] = w * CAB + (r & 3) * 8;
+    offB[blk] = (S * w) * CBB + (r & 3) * 8;               // + kw * CBB + slot * ROWB (+ 32 per channel tile)
+  }
+  f32x4 acc[NT][CA16][CB16];
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int ca = 0; ca < CA16; ++ca)
+#pragma unroll
+      for (int cb = 0; cb < CB16; ++cb) acc[k][ca][cb] = (f32x4){0, 0, 0, 0};
+
+  const bf16_t* __restrict__ Pm = reinterpret_cast<const bf16_t*>(a.P);
+  const bf16_t* __restrict__ Gm = reinterpret_cast<const bf16_t*>(a.G);
+  // XCD-aware unit walk: block b runs on XCD b % 8; every XCD sweeps its own eighth of the units front to back
+  const int nblk = gridDim.x;
+  int u_first, u_step, u_end;
+  if ((nblk & 7) == 0) {
+    const int per = (a.nunits + 7) >> 3;
+    const int lo = (blockIdx.x & 7) * per;
+    u_first = lo + (blockIdx.x >> 3) * 4 + wv; u_step = (nblk >> 3) * 4; u_end = min(a.nunits, lo + per);
+  } else { u_first = blockIdx.x * 4 + wv; u_step = nblk * 4; u_end = a.nunits; }
+  const int nstrips = a.Hp / a.HS;
+  const int nq = a.HS + 1;                                  // steps of a unit: the priming step + one per P row
+
+  // registers of the step in flight
+  Vec16 gv[GV], pv[PV];
+  auto issue = [&](int u, int q) {
+    const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
+    // G rows [top - S + 1, top], top = last row of P row h0 + q - 1
+    const int top = S * (h0 + q - 1) - PAD + KS - 1;
+#pragma unroll
+    for (int k = 0; k < GV; ++k) {
+      const int byte = (lane + 64 * k) * 16;
+      const int rr = byte / grow_bytes, off = byte - rr * grow_bytes;
+      const int row = top - S + 1 + rr;
+      gv[k] = Vec16{{0, 0, 0, 0}};
+      if (rr < S && row >= 0 && row < a.Hg)
+        gv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(Gm) + (((long)n * a.Hg + row) * Wg) * CBB + off);
+    }
+    if (q > 0) {
+#pragma unroll
+      for (int k = 0; k < PV; ++k)
+        pv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(Pm) + (((long)n * a.Hp + (h0 + q - 1)) * WP) * CAB + (lane + 64 * k) * 16);
+    }
+  };
+  auto commit = [&](int u, int q) {
+    const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
+    const int top = S * (h0 + q - 1) - PAD + KS - 1;
+#pragma unroll
+    for (int k = 0; k < GV; ++k) {
+      const int byte = (lane + 64 * k) * 16;
+      const int rr = byte / grow_bytes, off = byte - rr * grow_bytes;
+      if (rr < S) {
+        const int row = top - S + 1 + rr;
+        Vec16 v = gv[k];
+        if (PRO_G && row >= 0 && row < a.Hg) {
+          float f[8];
+          Elem<bf16_t>::unpack(v, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * gsc[j] + gsh[j], g_lo);
+          v = Elem<bf16_t>::pack(f);
+        }
+        const int slot = (row + 4 * NSLOT) % NSLOT;
+        *reinterpret_cast<Vec16*>(ring + slot * ROWB + PAD * CBB + off) = v;
+      }
+    }
+    if (q > 0) {
+#pragma unroll
+      for (int k = 0; k < PV; ++k) {
+        Vec16 v = pv[k];
+        if (PRO_P) {
+          float f[8];
+          Elem<bf16_t>::unpack(v, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * psc[j] + psh[j], p_lo);
+          v = Elem<bf16_t>::pack(f);
+        }
+        *reinterpret_cast<Vec16*>(prow + (lane + 64 * k) * 16) = v;
+      }
+    }
+  };
+
+  int u = u_first, q = 0;
+  if (u < u_end) issue(u, 0);
+  while (u < u_end) {
+    commit(u, q);
+    // the next step of the flat (unit, step) sequence goes in flight
+    int un = u, qn = q + 1;
+    if (qn == nq) { un = u + u_step; qn = 0; }
+    if (un < u_end) issue(un, qn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q > 0) {
+      const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
+      const int first = S * (h0 + q - 1) - PAD;             // G row of tap row kh = 0
+      Vec16 af[CA16];
+#pragma unroll
+      for (int ca = 0; ca < CA16; ++ca) af[ca] = FragOps<bf16_t>::load(prow, offA[0] + 32 * ca, offA[1] + 32 * ca);
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+        const char* rowp = ring + ((first + kh + 4 * NSLOT) % NSLOT) * ROWB;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+#pragma unroll
+          for (int cb = 0; cb < CB16; ++cb) {
+            const Vec16 bf = FragOps<bf16_t>::load(rowp, offB[0] + kw * CBB + 32 * cb, offB[1] + kw * CBB + 32 * cb);
+#pragma unroll
+            for (int ca = 0; ca < CA16; ++ca) acc[kh * KS + kw][ca][cb] = mma_bf16(af[ca], bf, acc[kh * KS + kw][ca][cb]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u = un; q = qn;
+  }
+
+  // ---- flush: the four waves add their accumulators in LDS (wave order: deterministic), the block stores one partial image.
+  // D fragment: lane (r, gq) holds D[a = 4gq + j][b = r]
+  float* img = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int ca = 0; ca < CA16; ++ca)
+#pragma unroll
+          for (int cb = 0; cb < CB16; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float* p = img + (k * CA16 * 16 + ca * 16 + 4 * gq + j) * (CB16 * 16) + cb * 16 + r;
+              *p = (w == 0 ? 0.f : *p) + acc[k][ca][cb][j];
+            }
+    }
+    __syncthreads();
+  }
+  float* dst = a.part + (long)blockIdx.x * WSIZE;
+  for (int i = t; i < WSIZE / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(img)[i];
+}
+
+template <int CA16, bool PRO_P, bool PRO_G>
+static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
+  constexpr int KS = 4, S = 2, WP = 32, CB16 = 1;
+  constexpr int WL = S * (WP - 1) + KS;
+  constexpr size_t lds = 4 * (size_t)((KS + S) * WL * CB16 * 32 + WP * CA16 * 32);
+  auto kern = &wgrad_stream_kernel<KS, S, 1, WP, CA16, CB16, PRO_P, PRO_G>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("wgrad_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, s, a);
+  return check_launch("wgrad_stream");
+}
+
+// Returns 1 when the launch was taken (kernel + reduce enqueued), 0 when the shape is not this kernel's, <0 on error.  MMVAE_WSTREAM=0: off
+int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s) {
+  static const int enabled = [] { const char* e = getenv("MMVAE_WSTREAM"); return e ? atoi(e) : 1; }();
+  if (!enabled || dt != DT_BF16 || a.P_planar || a.G_planar || !a.scratch) return 0;
+  if (a.ksz != 4 || a.stride != 2 || a.pad != 1 || a.ntaps != 16) return 0;
+  if (a.Wp != 32 || a.Wg != 64 || a.Hg != 2 * a.Hp || a.Cb != 16 || (a.Ca != 16 && a.Ca != 32)) return 0;
+  if (a.Cb_valid != a.Cb || a.Ca_valid != a.Ca) return 0;
+  for (int t = 0; t < 16; ++t) if (a.tap_off[t] != t) return 0;
+  WStreamArgs b; memset(&b, 0, sizeof(b));
+  b.P = a.P; b.G = a.G; b.part = a.scratch;
+  b.proP_scale = a.proP_scale; b.proP_shift = a.proP_shift; b.proP_relu = a.proP_relu;
+  b.proG_scale = a.proG_scale; b.proG_shift = a.proG_shift; b.proG_relu = a.proG_relu;
+  b.N = a.N; b.Hp = a.Hp; b.Hg = a.Hg; b.Wg = a.Wg;
+  b.HS = a.Hp % 16 == 0 ? 16 : a.Hp;
+  b.nunits = a.N * (a.Hp / b.HS);
+  int gx = 512;                                             // two 4-wave blocks per CU
+  while (gx > 8 && (long)gx * 4 > b.nunits) gx -= 8;
+  const int wsize = 16 * a.Ca * a.Cb;
+  if ((size_t)gx * wsize * 4 > kWgradScratchBytes) return 0;
+  const bool pp = a.proP_scale != nullptr, pg = a.proG_scale != nullptr;
+  int rc;
+  if (a.Ca == 16) rc = pp ? (pg ? launch_wstream_t<1, true, true>(b, gx, s) : launch_wstream_t<1, true, false>(b, gx, s))
+                          : (pg ? launch_wstream_t<1, false, true>(b, gx, s) : launch_wstream_t<1, false, false>(b, gx, s));
+  else rc = pp ? (pg ? launch_wstream_t<2, true, true>(b, gx, s) : launch_wstream_t<2, true, false>(b, gx, s))
+               : (pg ? launch_wstream_t<2, false, true>(b, gx, s) : launch_wstream_t<2, false, false>(b, gx, s));
+  if (rc < 0) return rc;
+  WgradReduceArgs u; memset(&u, 0, sizeof(u));
+  u.part = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.nparts = gx;
+  u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid; u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
+  for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
+  const int rc2 = launch_wgrad_reduce(u, s);
+  return rc2 < 0 ? rc2 : 1;
+}
+
+}  // namespace mmvae

@@ -65,6 +65,7 @@ struct WgradArgs {
   int TA16, TB16, TG;      // tile config chosen by the launcher
 };
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
+int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s);   // conv_wstream.hip: 1 = taken, 0 = not this kernel's shape, <0 error
 
 // ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
 // A tile is up to TP (128, or 64/32 for wgrad on tiny feature maps) q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.

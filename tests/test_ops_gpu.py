@@ -38,6 +38,7 @@ CONFIGS = [
     (16, 16, 1, 1, 0, 0, 64, 40), (16, 16, 4, 2, 1, 1, 32, 36),                                  # > 1024 pixel tiles
     (16, 16, 3, 1, 1, 0, 64, 2), (32, 32, 4, 2, 1, 1, 16, 4), (16, 32, 3, 2, 1, 0, 64, 2),       # 256/512-pixel row tiles, LDS-staged epilogue
     (32, 16, 3, 1, 1, 0, 32, 3), (16, 16, 4, 2, 1, 0, 64, 2),
+    (32, 16, 4, 2, 1, 1, 32, 5), (16, 16, 4, 2, 1, 1, 32, 70),                                   # streaming weight gradient (32x32 -> 64x64)
 ]
 
 
@@ -139,7 +140,7 @@ def test_conv_ops_match_torch(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4], CONFIGS[17], CONFIGS[22], CONFIGS[26], CONFIGS[12]],
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4], CONFIGS[17], CONFIGS[22], CONFIGS[26], CONFIGS[12], CONFIGS[27], CONFIGS[-2], CONFIGS[-1]],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv_ops_with_fused_bn_relu_prologue(cfg, dt):
     errs = run_config(cfg, dt, prologue=True)
