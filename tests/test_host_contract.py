@@ -65,6 +65,32 @@ def test_quantise_frames_matches_kmeans_predict(pkg):
         np.testing.assert_allclose(image.cpu().numpy(), (ref.astype(np.float32) - 0.0521) / 0.2222, rtol=1e-6)
 
 
+def _kmeans_fixture(q):
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"kmeans_q{q}.npz"))
+    return d["frames"], d["centres"], d["labels"].astype(np.int64), float(d["data_mean"]), float(d["data_std"])
+
+
+@pytest.mark.parametrize("q", [2, 4])
+def test_kmeans_fixture_is_nearest_centre(q):
+    """CPU: the committed scikit-learn outputs (oracle/make_kmeans_fixture.py: KMeans.fit / .predict as utils.py:287 and main.py:25
+    call them) are what the device kernel's rule -- nearest centre on the ToTensor scale, lowest index on ties -- gives."""
+    frames, centres, labels, mean, std = _kmeans_fixture(q)
+    x = frames.astype(np.float32) / 255.0
+    ref = np.argmin((x[..., None] - centres.astype(np.float32)) ** 2, axis=-1)
+    assert np.array_equal(ref, labels)
+    assert abs(labels.mean() - mean) < 1e-4 and abs(labels.std() - std) < 1e-4          # utils.py:296-305 (rounded to 4 digits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("q", [2, 4])
+def test_quantise_frames_matches_sklearn_kmeans_predict(pkg, q):
+    """The device-side input step against scikit-learn's own KMeans.predict on the same frames (fixture: data only)."""
+    frames, centres, labels, mean, std = _kmeans_fixture(q)
+    got, image = pkg.quantise_frames(torch.from_numpy(frames).cuda(), centres, mean, std)
+    assert np.array_equal(got.cpu().numpy(), labels)
+    np.testing.assert_allclose(image.cpu().numpy(), (labels.astype(np.float32) - np.float32(mean)) / np.float32(std), rtol=1e-6)
+
+
 def test_clips_from_npz_array_layout(pkg):
     """The reference reads (N, C, W, H), transposes to (N, H, W, C) (movingmnistdataset.py:15) and ToTensor makes each sample
     (C, H, W): restated with numpy here, step by step, and compared with the one-transpose form the loader uses."""
@@ -128,13 +154,18 @@ def test_fused_adam_resume(pkg, oracle, tmp_path):
     assert oc._t == ob._t == 2 and torch.equal(oc._m, ob._m) and torch.equal(oc._v, ob._v) and torch.equal(c._flat, b._flat)
     run(c, oc, [2])
     torch.cuda.synchronize()
-    # decoder.conv2.bias feeds a BatchNorm: its gradient is analytically zero, Adam turns the rounding noise into +-lr.
-    # The same happens to single elements with a (near-)zero gradient (float-atomic summation order differs from run to
-    # run), so the comparison is a relative L2 norm per tensor, not an element-wise maximum.
+    # Adam's first steps move EVERY element by ~lr in the direction of its gradient's sign, so an element whose gradient is (near) zero --
+    # decoder.conv2.bias feeds a BatchNorm (analytically zero gradient), BatchNorm biases start at 0 -- turns last-bit differences
+    # (float-atomic summation order differs from run to run) into visible parameter differences.  Bound the trajectory, not the bits:
+    # the update of the three steps agrees within 2 % in relative L2 over all parameters, every element within 5 lr.
     pa = dict(a.named_parameters())
-    errs = {k: ((p - pa[k]).norm() / pa[k].norm()).item() for k, p in c.named_parameters() if k != "decoder.conv2.bias"}
-    worst = max(errs, key=errs.get)
-    assert errs[worst] < 1e-3, (worst, errs[worst])
+    num = den = 0.0
+    for k, p in c.named_parameters():
+        p = p.detach()
+        assert (p - pa[k].detach()).abs().max().item() <= 5e-3, k
+        num += float(((p - pa[k].detach()).double() ** 2).sum())
+        den += float(((pa[k].detach() - init[k].to(dev)).double() ** 2).sum())
+    assert num <= (0.02 ** 2) * den, (num, den)
 
 
 def test_repr_is_the_reference_text(pkg):
