@@ -189,6 +189,30 @@ MMVAE_API int mmvae_conv2d_dgrad(int dtype, int transposed, const void* dy, cons
 MMVAE_API int mmvae_conv2d_wgrad(int dtype, int transposed, const void* x, const void* dy, float* dweight, int N, int H, int W, int Cin,
                        int Cout, int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu,
                        void* scratch, void* stream);
+/* ---- BatchNorm2d in training mode and the 1-channel stem, op level (what a maintainer binds instead of torch.nn.BatchNorm2d,
+ * model.py:14,20,30,95,..., and of encoder.conv1 + encoder.bn1, model.py:94-95,103)
+ * Tensors are NHWC [npix][C] of `dtype`; statistics, parameters and their gradients are f32.
+ * scratch: MMVAE_BN_SCRATCH_BYTES of device memory, caller-owned (partial sums of the two-pass reductions, coefficient rows). */
+#define MMVAE_BN_SCRATCH_BYTES (16u << 20)
+/* out = relu?( (y - mean) * istd * gamma + beta ) with the statistics of this batch (biased variance); running_mean / running_var
+ * (nullable) are updated with `momentum` and the unbiased variance, *nbt (nullable) += 1; save_mean / save_istd (C floats each)
+ * are kept for the backward pass. */
+MMVAE_API int mmvae_batchnorm_fwd(int dtype, const void* y, int64_t npix, int C, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, int64_t* nbt, float momentum, float eps, int relu, void* out, float* save_mean, float* save_istd,
+                        void* scratch, void* stream);
+/* dy = d(loss)/dy, dgamma += , dbeta += ; dout is the gradient w.r.t. `out`; out (nullable): the forward result when a ReLU was
+ * fused (its sign is the mask), NULL for a plain BatchNorm. */
+MMVAE_API int mmvae_batchnorm_bwd(int dtype, const void* dout, const void* y, const void* out, int64_t npix, int C, const float* gamma,
+                        const float* save_mean, const float* save_istd, void* dy, float* dgamma, float* dbeta, void* scratch, void* stream);
+/* encoder.conv1: Conv2d(1 -> 32, k5 s2 p2, no bias) on x [N,S,S] of `dtype` -> y [N,S/2,S/2,32]; stats as mmvae_conv2d_fwd.
+ * scratch: >= 2 KB * sizeof(dtype) for the packed weights. */
+MMVAE_API int mmvae_stem_fwd(int dtype, const void* x, const float* weight, void* y, int N, int S, float* stats, void* scratch, void* stream);
+/* Backward of relu(bn(conv1(x))) w.r.t. the parameters in ONE pass over g and y0 (stem_bwd.hip): g = gradient at the block input
+ * (post-ReLU activation), y0 = conv1 output, (bn_scale, bn_shift) = gamma*istd, beta - mean*gamma*istd.
+ * dweight (32,1,5,5) +=, dgamma +=, dbeta +=.  S in {64, 32, 16}.  scratch: MMVAE_BN_SCRATCH_BYTES. */
+MMVAE_API int mmvae_stem_bwd(int dtype, const void* g, const void* y0, const void* x, const float* weight, const float* gamma,
+                   const float* bn_scale, const float* bn_shift, const float* save_mean, const float* save_istd, float* dweight,
+                   float* dgamma, float* dbeta, int N, int S, void* scratch, void* stream);
 /* ---- last up-block + tail conv, one output plane (decoder.uplayerN -> decoder.conv2, reference model.py:86-88,193) ----
  * y2, ys: the two branch outputs [N,H,W,16] of `dtype` (BatchNorm not yet applied); (s2,b2), (ss,bs): per-channel f32
  * scale/shift of their BatchNorms; the block output is x = relu(y2*s2+b2 + ys*ss+bs).  weight f32 (1,16,3,3), bias f32 (1).

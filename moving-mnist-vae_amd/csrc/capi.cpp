@@ -244,6 +244,72 @@ int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, fl
   if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st), sc);
   return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), sc);
 }
+// ---- op-level BatchNorm / stem (compositions of the kernels the network orchestrator launches)
+static_assert(MMVAE_BN_SCRATCH_BYTES >= (1024u * 3 * 512 + 8 * 512) * 4, "BatchNorm scratch: 1024 partial rows x 3 x C<=512 + coefficient rows");
+int mmvae_batchnorm_fwd(int dt, const void* y, int64_t npix, int C, const float* gamma, const float* beta, float* rm, float* rv, int64_t* nbt,
+                        float momentum, float eps, int relu, void* out, float* save_mean, float* save_istd, void* scratch, void* st) {
+  if (!scratch || !save_mean || !save_istd || C < 1 || C > 512 || npix < 1) { set_error("batchnorm_fwd: bad arguments (C <= 512, scratch and save_* required)"); return MMVAE_ERR_ARG; }
+  float* part = static_cast<float*>(scratch);
+  float* coef = part + 1024L * 3 * 512;              // scale, shift
+  const int np = launch_chan_stats_nhwc(dt, y, npix, C, part, S(st));
+  if (np < 0) return np;
+  BnFinalizeArgs f;
+  f.partials = part; f.nparts = np; f.C = C; f.count = (double)npix; f.gamma = gamma; f.beta = beta; f.running_mean = rm; f.running_var = rv;
+  f.nbt = reinterpret_cast<long long*>(nbt); f.mean = save_mean; f.istd = save_istd; f.scale = coef; f.shift = coef + C; f.momentum = momentum; f.eps = eps;
+  int rc = launch_bn_finalize(f, S(st));
+  if (rc < 0) return rc;
+  return launch_affine_act(dt, y, coef, coef + C, relu, out, npix, C, S(st));
+}
+int mmvae_batchnorm_bwd(int dt, const void* dout, const void* y, const void* out, int64_t npix, int C, const float* gamma, const float* save_mean,
+                        const float* save_istd, void* dy, float* dgamma, float* dbeta, void* scratch, void* st) {
+  if (!scratch || C < 1 || C > 512 || npix < 1) { set_error("batchnorm_bwd: bad arguments (C <= 512, scratch required)"); return MMVAE_ERR_ARG; }
+  float* part = static_cast<float*>(scratch);
+  float* coef = part + 1024L * 3 * 512;              // A, B, C
+  const int np = launch_bn_bwd_reduce(dt, dout, out, nullptr, nullptr, y, nullptr, npix, C, part, S(st));
+  if (np < 0) return np;
+  BnBwdFinalizeArgs f; std::memset(&f, 0, sizeof(f));
+  f.partials = part; f.nparts = np; f.C = C; f.which = 0; f.ny = 1; f.count = (double)npix; f.gamma = gamma; f.mean = save_mean; f.istd = save_istd;
+  f.dgamma = dgamma; f.dbeta = dbeta; f.coefA = coef; f.coefB = coef + C; f.coefC = coef + 2 * C;
+  int rc = launch_bn_bwd_finalize(f, S(st));
+  if (rc < 0) return rc;
+  return launch_bn_bwd_apply(dt, dout, out, nullptr, nullptr, y, coef, coef + C, coef + 2 * C, dy, nullptr, nullptr, nullptr, nullptr, nullptr, npix, C, S(st));
+}
+int mmvae_stem_fwd(int dt, const void* x, const float* w, void* y, int N, int Sz, float* stats, void* scratch, void* st) {
+  if (!scratch || N < 1 || Sz < 9 || Sz > 64) { set_error("stem_fwd: bad arguments"); return MMVAE_ERR_ARG; }
+  const int H1 = (Sz + 4 - 5) / 2 + 1;
+  const int cpad = dt == DT_F32 ? 4 : 8;
+  PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+  pa.src = w; pa.dst = scratch;
+  pa.cols = 32; pa.K = cpad; pa.K_valid = 1; pa.ntaps = 25; pa.s_col = 25; pa.s_k = 25; pa.scale = 1.f;
+  for (int t = 0; t < 25; ++t) pa.tap_off[t] = t;
+  int rc = launch_pack(dt, pa, S(st));
+  if (rc < 0) return rc;
+  GatherArgs a; std::memset(&a, 0, sizeof(a));
+  a.x = x; a.w = scratch; a.y = y; a.stats = stats;
+  a.x_planar = 2; a.x_planes = 1;
+  a.N = N; a.Hi = Sz; a.Wi = Sz; a.Cin = cpad; a.Ho = H1; a.Wo = H1; a.Cout = 32; a.SI = 2; a.SO = 1;
+  a.nphase = 1; a.phases[0] = Phase{0, 0, H1, H1, 25, 0, 0};
+  for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw) a.taps[kh * 5 + kw] = Tap{kh - 2, kw - 2};
+  return launch_gather_gemm(dt, dt, a, S(st));
+}
+int mmvae_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* w, const float* gamma, const float* bn_scale,
+                   const float* bn_shift, const float* save_mean, const float* save_istd, float* dw, float* dgamma, float* dbeta, int N, int Sz,
+                   void* scratch, void* st) {
+  if (!scratch || N < 1) { set_error("stem_bwd: bad arguments"); return MMVAE_ERR_ARG; }
+  if (!stem_bwd_fusable(Sz)) { set_error("stem_bwd: image size %d unsupported (64, 32, 16)", Sz); return MMVAE_ERR_UNSUPPORTED; }
+  const int H1 = (Sz + 4 - 5) / 2 + 1;
+  // carve: R (1024 doubles) | gram partials (1024 x part floats) | backward partials (the rest)
+  double* R = static_cast<double*>(scratch);
+  float* gram = reinterpret_cast<float*>(R + 1024);
+  const long gram_floats = 1024L * stem_bwd_part_floats();
+  float* part = gram + gram_floats;
+  const long part_floats = (long)(MMVAE_BN_SCRATCH_BYTES - 1024 * 8) / 4 - gram_floats;
+  int rc = launch_stem_gram(dt, x, gram, gram_floats, R, N, Sz, H1, H1, S(st));
+  if (rc < 0) return rc;
+  const int np = launch_stem_bwd(dt, g, y0, x, bn_scale, bn_shift, part, part_floats, N, Sz, H1, H1, S(st));
+  if (np < 0) return np;
+  return launch_stem_bwd_finalize(part, np, R, w, nullptr, (double)N * H1 * H1, gamma, save_mean, save_istd, dgamma, dbeta, dw, S(st));
+}
 int mmvae_tail_join_fwd(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
                         const float* w, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* st) {
   return launch_tail_join_fwd(dt, y2, s2, b2, ys, ss, bs, w, bias, r_raw, stats, N, H, W, S(st));
