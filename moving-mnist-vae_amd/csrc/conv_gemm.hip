@@ -1048,7 +1048,8 @@ int pack_batch_flush(int dt, hipStream_t s) {
   for (int j0 = 0; j0 < g_pack_n; j0 += kPackJobsPerLaunch) {
     PackMulti m; m.njobs = g_pack_n - j0 < kPackJobsPerLaunch ? g_pack_n - j0 : kPackJobsPerLaunch; m.pad = 0;
     for (int j = 0; j < m.njobs; ++j) m.jobs[j] = g_pack_jobs[j0 + j];
-    dim3 grid(32, m.njobs), block(256);
+    // 128 blocks per job: the largest weight (256 x 256 x 9) sets the launch's duration, its gather reads are latency-bound
+    dim3 grid(128, m.njobs), block(256);
     if (dt == DT_F32) hipLaunchKernelGGL((pack_multi_kernel<float>), grid, block, 0, s, m);
     else hipLaunchKernelGGL((pack_multi_kernel<bf16_t>), grid, block, 0, s, m);
     int rc = check_launch("pack_multi");

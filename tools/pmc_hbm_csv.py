@@ -1,0 +1,56 @@
+"""Developer tool: HBM bytes per launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected separately as the
+MI355X guide prescribes) of `bench.py --steps 1 --warmup 1` -> rows of profiles/rNN_pmc_hbm.csv, keyed by the build hash so that
+bench.py only quotes them for the build they were measured on.
+  fetch_bytes = 2 * FETCH_SIZE * 1024   (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes; unit KB)
+  write_bytes = WRITE_SIZE * 1024
+keys: uplayer5.conv2.fwd   the last patch_conv_kernel dispatch before tail_join_fwd_kernel (decoder.uplayer5.0.conv2 forward)
+      uplayer5.join_bwd_apply   the second tail_join_bwd_kernel dispatch of the step (apply pass)
+      __step__   every dispatch of the last train step (between two Adam kernels)
+usage: python tools/pmc_hbm_csv.py <fetch counter_collection.csv> <write counter_collection.csv> <frames> > profiles/rNN_pmc_hbm.csv"""
+import csv
+import importlib
+import os
+import sys
+from collections import OrderedDict
+
+sys.path.insert(0, os.getcwd())
+
+
+def per_dispatch(path, counter):
+    d = OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = int(r["Dispatch_Id"])
+        name, val = d.get(k, (r["Kernel_Name"], 0.0))
+        d[k] = (name, val + float(r["Counter_Value"]))
+    return [d[k] for k in sorted(d)]
+
+
+def last_step(rows):
+    ends = [i for i, (n, _) in enumerate(rows) if "adam" in n]
+    return rows[ends[-2] + 1:ends[-1] + 1]
+
+
+def pick(step):
+    names = [n for n, _ in step]
+    out = {"__step__": sum(v for _, v in step)}
+    j = next(i for i, n in enumerate(names) if "tail_join_fwd_kernel" in n)
+    i = max(k for k in range(j) if "patch_conv_kernel" in names[k])
+    out["uplayer5.conv2.fwd"] = step[i][1]
+    tb = [k for k, n in enumerate(names) if "tail_join_bwd_kernel" in n]
+    out["uplayer5.join_bwd_apply"] = step[tb[1]][1]
+    return out
+
+
+def main(fetch_csv, write_csv, frames):
+    build = importlib.import_module("moving-mnist-vae_amd._lib").build_hash()
+    f = pick(last_step(per_dispatch(fetch_csv, "FETCH_SIZE")))
+    w = pick(last_step(per_dispatch(write_csv, "WRITE_SIZE")))
+    print("build,frames,key,fetch_bytes,write_bytes")
+    for k in ("uplayer5.conv2.fwd", "uplayer5.join_bwd_apply", "__step__"):
+        print(f"{build},{int(frames)},{k},{2 * f[k] * 1024:.0f},{w[k] * 1024:.0f}")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
