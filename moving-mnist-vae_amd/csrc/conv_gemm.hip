@@ -517,8 +517,10 @@ bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, i
   if (!deep2_enabled()) return false;
   const int ES = dt == DT_F32 ? 4 : 2;
   const int cpt = Cin * ES / 64;
-  if (Cin < 64 || (Cin * ES) % 64 != 0 || (cpt != (ES == 2 ? 2 : 4) && cpt != (ES == 2 ? 4 : 8) && cpt != (ES == 2 ? 8 : 16))) return false;   // Cin 64, 128, 256
-  if (Cout < 64 || Cout % 64 != 0 || (Cout > 256 && Cout % 256 != 0)) return false;
+  const int c0 = ES == 2 ? 1 : 2;                   // 64-byte chunks of a tap at Cin = 32
+  if (Cin < 32 || (Cin * ES) % 64 != 0 || (cpt != c0 && cpt != 2 * c0 && cpt != 4 * c0 && cpt != 8 * c0)) return false;   // Cin 32, 64, 128, 256
+  if (Cout < 32 || Cout % 32 != 0 || (Cout > 256 && Cout % 256 != 0)) return false;
+  if (Cin < 64 && Cout < 64) return false;          // the 16/32-channel layers are the patch-tile kernel's (weights resident in LDS)
   const int hw = Hq * Wq;
   if (hw < 1 || hw > 128 || Hq > 255 || Wq > 255 || ntaps_all < 1 || ntaps_all > kMaxTaps) return false;
   const int npt_min = hw > 64 ? 8 : hw > 32 ? 4 : 2;

@@ -1,5 +1,5 @@
 """Developer tool (GPU box): every channel-heavy (Cin, Cout >= 64) convolution of the config-2 network timed in isolation through the
-C ABI (forward and dgrad), with its FLOP count and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak.
+C ABI (forward and data gradient), with its FLOP count and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak.
 usage: python tools/deep_probe.py [N=5120] [reps=20]"""
 import ctypes
 import importlib
@@ -13,6 +13,7 @@ L = importlib.import_module("moving-mnist-vae_amd._lib")
 
 # name, transposed, Cin, Cout, k, s, p, H (input side of the forward op)
 LAYERS = [
+    ("enc.layer2.conv1", 0, 32, 64, 3, 2, 1, 16),
     ("enc.layer2.conv2", 0, 64, 64, 3, 1, 1, 8),
     ("enc.layer3.conv1", 0, 64, 128, 3, 2, 1, 8),
     ("enc.layer3.down", 0, 64, 128, 1, 2, 0, 8),
@@ -26,6 +27,8 @@ LAYERS = [
     ("dec.up2.conv1", 0, 128, 64, 1, 1, 0, 4),
     ("dec.up2.conv2", 1, 64, 64, 4, 2, 1, 4),
     ("dec.up2.upsample", 1, 128, 64, 4, 2, 1, 4),
+    ("dec.up3.conv1", 0, 64, 32, 1, 1, 0, 8),
+    ("dec.up3.upsample", 1, 64, 32, 4, 2, 1, 8),
 ]
 
 
@@ -59,14 +62,14 @@ def main(N=5120, reps=20):
                                         P(scratch.data_ptr()), P(s))
             L.check(rc, name)
 
-        for op, fn in (("fwd", fwd),):
+        for op, fn in (("fwd", fwd), ("dgrad", dgrad)):
             fn(True)
-            fn(False)
+            fn(op == "dgrad")
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                fn(False)
+                fn(op == "dgrad")       # the dgrad entry point packs on every call (one small extra launch)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
