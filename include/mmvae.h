@@ -213,6 +213,13 @@ MMVAE_API int mmvae_stem_fwd(int dtype, const void* x, const float* weight, void
 MMVAE_API int mmvae_stem_bwd(int dtype, const void* g, const void* y0, const void* x, const float* weight, const float* gamma,
                    const float* bn_scale, const float* bn_shift, const float* save_mean, const float* save_istd, float* dweight,
                    float* dgamma, float* dbeta, int N, int S, void* scratch, void* stream);
+/* ConvTranspose2d backward in one pass over dy (bf16; Cin = Cout = 16, k4 s2 p1, 32x32 -> 64x64; else MMVAE_ERR_UNSUPPORTED):
+ * dweight (Cin,Cout,4,4) += , dx [N,H,W,Cin] = d(loss)/dx  (+ x2 (x) w2: x2 [N,H,W,16], w2 f32 (Cin,16,1,1), both nullable).
+ * pro_*: as in mmvae_conv2d_wgrad (applied to x).  scratch: (numel(weight) + numel(w2)) * sizeof(dtype) for the packed weights;
+ * wscratch: MMVAE_WGRAD_SCRATCH_BYTES. */
+MMVAE_API int mmvae_convT_bwd_fused(int dtype, const void* x, const void* dy, const float* weight, float* dweight, void* dx, int N, int H, int W,
+                          int Cin, int Cout, int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu,
+                          const void* x2, const float* w2, void* scratch, void* wscratch, void* stream);
 /* ---- last up-block + tail conv, one output plane (decoder.uplayerN -> decoder.conv2, reference model.py:86-88,193) ----
  * y2, ys: the two branch outputs [N,H,W,16] of `dtype` (BatchNorm not yet applied); (s2,b2), (ss,bs): per-channel f32
  * scale/shift of their BatchNorms; the block output is x = relu(y2*s2+b2 + ys*ss+bs).  weight f32 (1,16,3,3), bias f32 (1).

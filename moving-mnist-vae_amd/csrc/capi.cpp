@@ -244,6 +244,26 @@ int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, fl
   if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st), sc);
   return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), sc);
 }
+int mmvae_convT_bwd_fused(int dt, const void* x, const void* dy, const float* w, float* dw, void* dx, int N, int H, int W, int Cin, int Cout, int k,
+                          int s, int p, const float* ps, const float* pb, int relu, const void* x2, const float* w2, void* scratch, void* wscratch,
+                          void* st) {
+  const ConvGeom g = geom_for(1, Cin, Cout, k, s, p);
+  const int Ho = out_size(1, H, k, s, p), Wo = out_size(1, W, k, s, p);
+  if (!scratch || !wscratch) { set_error("convT_bwd_fused: scratch buffers required"); return MMVAE_ERR_ARG; }
+  if (!op_bwd_fusable(dt, g, N, H, W, Ho, Wo)) { set_error("convT_bwd_fused: shape not supported (bf16, 16 -> 16 channels, k4 s2 p1, 32x32 -> 64x64)"); return MMVAE_ERR_UNSUPPORTED; }
+  char* sc = static_cast<char*>(scratch);
+  int rc = op_pack_down(dt, g, w, sc, S(st)); if (rc < 0) return rc;
+  const void* w2p = nullptr;
+  if (x2 && w2) {
+    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
+    pa.src = w2; pa.dst = sc + (size_t)Cin * Cout * k * k * dtype_size(dt); pa.cols = Cin; pa.K = 16; pa.ntaps = 1; pa.s_col = 16; pa.s_k = 1; pa.scale = 1.f; pa.tap_off[0] = 0;
+    rc = launch_pack(dt, pa, S(st)); if (rc < 0) return rc;
+    w2p = pa.dst;
+  }
+  rc = op_run_bwd_fused(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, sc, dx, w2p ? x2 : nullptr, w2p, dw, S(st), static_cast<float*>(wscratch));
+  if (rc == 0) { set_error("convT_bwd_fused: not taken"); return MMVAE_ERR_UNSUPPORTED; }
+  return rc < 0 ? rc : MMVAE_OK;
+}
 // ---- op-level BatchNorm / stem (compositions of the kernels the network orchestrator launches)
 static_assert(MMVAE_BN_SCRATCH_BYTES >= (1024u * 3 * 512 + 8 * 512) * 4, "BatchNorm scratch: 1024 partial rows x 3 x C<=512 + coefficient rows");
 int mmvae_batchnorm_fwd(int dt, const void* y, int64_t npix, int C, const float* gamma, const float* beta, float* rm, float* rv, int64_t* nbt,

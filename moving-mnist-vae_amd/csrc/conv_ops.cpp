@@ -142,4 +142,34 @@ int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws
   return launch_wgrad(dt, a, s);
 }
 
+static void wgrad_args(WgradArgs& a, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
+                       const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, float* scratch, float scale) {
+  std::memset(&a, 0, sizeof(a));
+  const int kk = g.k * g.k;
+  a.P = P; a.G = G; a.dW = dW; a.scratch = scratch;
+  a.proP_scale = proP_s; a.proP_shift = proP_b; a.proP_relu = proP_relu;
+  a.proG_scale = proG_s; a.proG_shift = proG_b; a.proG_relu = proG_relu;
+  a.N = N; a.Hp = Hs; a.Wp = Ws; a.Ca = g.D0; a.Hg = Hl; a.Wg = Wl; a.Cb = g.D1; a.Cb_valid = g.D1; a.Ca_valid = g.D0;
+  a.stride = g.s; a.pad = g.p; a.ksz = g.k; a.sA = g.D1 * kk; a.sB = kk; a.ntaps = kk; a.scale = scale;
+  for (int t = 0; t < kk && t < 25; ++t) a.tap_off[t] = t;
+}
+
+bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl) {
+  if (g.k * g.k > 25) return false;
+  WgradArgs a;
+  float dummy = 0.f;
+  wgrad_args(a, g, N, nullptr, Hs, Ws, nullptr, nullptr, 0, nullptr, Hl, Wl, nullptr, nullptr, 0, nullptr, &dummy, 1.f);
+  return dgrad_wgrad_stream_shape(dt, a);
+}
+
+int op_run_bwd_fused(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
+                     const void* G, int Hl, int Wl, const void* packed_down, void* dP, const void* x2, const void* w2_packed, float* dW,
+                     hipStream_t s, float* scratch, float scale) {
+  if (g.k * g.k > 25) return 0;
+  WgradArgs a;
+  wgrad_args(a, g, N, P, Hs, Ws, proP_s, proP_b, proP_relu, G, Hl, Wl, nullptr, nullptr, 0, dW, scratch, scale);
+  a.M = a.N * a.Hp * a.Wp;
+  return try_dgrad_wgrad_stream(dt, a, packed_down, dP, x2, w2_packed, s);
+}
+
 }  // namespace mmvae

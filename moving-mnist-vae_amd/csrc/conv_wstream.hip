@@ -28,18 +28,29 @@ struct WStreamArgs {
   int N, Hp, Hg, Wg;
   int HS;                    // P rows per strip (divides Hp)
   int nunits;                // N * Hp / HS
+  // fused data gradient (DG): dx[n,h,w,a] = sum_{kh,kw,b} G[n, S*h+kh-PAD, S*w+kw-PAD, b] * wd[a][kh*KS+kw][b]  (+ x2[n,h,w,:] . w2[a][:])
+  const void* wd;            // packed [Ca][KS*KS][Cb] of T (the conv's "down" form)
+  void* dx;                  // [N][Hp][WP][Ca] of T
+  const void* x2; const void* w2;   // optional second source on the P grid: x2 [N][Hp][WP][16], w2 packed [Ca][16]
 };
 
 // KS x KS taps, stride S, padding PAD; WP = P row width (32: one row per MFMA K-step); CA16, CB16: channel tiles of P and G
-template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G>
+// DG: the same pass also produces the data gradient w.r.t. P (the G rows a P row needs for its weight gradient are exactly the rows
+// its data gradient needs): the dy tensor is read ONCE for both.  Two taps (2 x 16 G channels) make one 16x16x32 MFMA K-step; the A
+// operand is the conv's packed "down" weights (8 fragments, loaded once), B fragments are plain 16-byte reads of ring pixels.
+// X2 (with DG): + the 1x1 shortcut's share, x2 (x) w2, from a second row staged per step (the block-input gradient in one kernel).
+template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
   static_assert(WP == 32, "one P row per K-step");
+  static_assert(!DG || (CA16 == 1 && CB16 == 1 && KS == 4), "fused data gradient: 16 -> 16 channels, 4x4 taps");
+  static_assert(!X2 || DG, "the second source rides on the data gradient");
   constexpr int CAB = CA16 * 32, CBB = CB16 * 32;          // bytes per P / G pixel
   constexpr int WL = S * (WP - 1) + KS;                    // G columns a P row reaches: -PAD .. S*(WP-1)+KS-1-PAD
   constexpr int ROWB = WL * CBB;                           // bytes per LDS G row
   constexpr int NSLOT = KS + S;                            // ring: the KS rows being multiplied + the S rows arriving
   constexpr int PB = WP * CAB;                             // bytes of a P row
-  constexpr int WAVE_LDS = NSLOT * ROWB + PB;
+  constexpr int X2B = X2 ? WP * 32 : 0;                    // bytes of an x2 row (16 channels)
+  constexpr int WAVE_LDS = NSLOT * ROWB + PB + X2B;
   constexpr int NT = KS * KS;
   constexpr int WSIZE = NT * CA16 * 16 * CB16 * 16;        // floats of a partial image
   static_assert(4 * WAVE_LDS >= WSIZE * 4, "the flush image aliases the rings");
@@ -47,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
   char* ring = smem + wv * WAVE_LDS;
   char* prow = ring + NSLOT * ROWB;
+  char* x2row = prow + PB;
   constexpr int Wg = S * WP;                               // G row width (the launcher checks it)
   constexpr int grow_bytes = Wg * CBB;                     // bytes of a G row in memory
   constexpr int GV = (S * grow_bytes + 1023) / 1024;       // 16-byte vectors per lane for the S rows of a step
@@ -89,6 +101,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
 #pragma unroll
       for (int cb = 0; cb < CB16; ++cb) acc[k][ca][cb] = (f32x4){0, 0, 0, 0};
 
+  Vec16 wdA[DG ? KS * KS / 2 : 1], w2A = Vec16{{0, 0, 0, 0}};
+  if constexpr (DG) {
+    // A[row a = r][k = 8gq ..]: taps (kh, 2kp) and (kh, 2kp + 1), 16 G channels each = 64 contiguous bytes of wd[a][tap][b]
+#pragma unroll
+    for (int pr = 0; pr < KS * KS / 2; ++pr)
+      wdA[pr] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.wd) + r * (KS * KS * 32) + pr * 64 + gq * 16);
+    if (X2 && gq < 2) w2A = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.w2) + r * 32 + gq * 16);
+  }
   const bf16_t* __restrict__ Pm = reinterpret_cast<const bf16_t*>(a.P);
   const bf16_t* __restrict__ Gm = reinterpret_cast<const bf16_t*>(a.G);
   // XCD-aware unit walk: block b runs on XCD b % 8; every XCD sweeps its own eighth of the units front to back
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
   const int nq = a.HS + 1;                                  // steps of a unit: the priming step + one per P row
 
   // registers of the step in flight
-  Vec16 gv[GV], pv[PV];
+  Vec16 gv[GV], pv[PV], xv = Vec16{{0, 0, 0, 0}};
   auto issue = [&](int u, int q) {
     const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
     // G rows [top - S + 1, top], top = last row of P row h0 + q - 1
@@ -121,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
 #pragma unroll
       for (int k = 0; k < PV; ++k)
         pv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(Pm) + (((long)n * a.Hp + (h0 + q - 1)) * WP) * CAB + (lane + 64 * k) * 16);
+      if constexpr (X2) xv = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.x2) + (((long)n * a.Hp + (h0 + q - 1)) * WP) * 32 + lane * 16);
     }
   };
   auto commit = [&](int u, int q) {
@@ -157,6 +178,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
         }
         *reinterpret_cast<Vec16*>(prow + (lane + 64 * k) * 16) = v;
       }
+      if constexpr (X2) *reinterpret_cast<Vec16*>(x2row + lane * 16) = xv;
     }
   };
 
@@ -188,6 +210,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
           }
         }
       }
+      if constexpr (DG) {
+        // D[a][pixel]: lane (r = pixel of the 16-pixel tile, gq) ends with channels a = 4gq .. 4gq+3
+        f32x4 dacc[WP / 16];
+#pragma unroll
+        for (int pt = 0; pt < WP / 16; ++pt) dacc[pt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+          const char* rowp = ring + ((first + kh + 4 * NSLOT) % NSLOT) * ROWB;
+#pragma unroll
+          for (int kp = 0; kp < KS / 2; ++kp)
+#pragma unroll
+            for (int pt = 0; pt < WP / 16; ++pt) {
+              const Vec16 b = *reinterpret_cast<const Vec16*>(rowp + (S * (16 * pt + r) + 2 * kp + (gq >> 1)) * CBB + (gq & 1) * 16);
+              dacc[pt] = mma_bf16(wdA[kh * (KS / 2) + kp], b, dacc[pt]);
+            }
+        }
+        if constexpr (X2) {
+#pragma unroll
+          for (int pt = 0; pt < WP / 16; ++pt) {
+            const Vec16 b = *reinterpret_cast<const Vec16*>(x2row + (16 * pt + r) * 32 + (gq & 1) * 16);     // k >= 16: w2A is zero there
+            dacc[pt] = mma_bf16(w2A, b, dacc[pt]);
+          }
+        }
+        bf16_t* drow = reinterpret_cast<bf16_t*>(a.dx) + (((long)n * a.Hp + (h0 + q - 1)) * WP) * 16 + 4 * gq;
+#pragma unroll
+        for (int pt = 0; pt < WP / 16; ++pt) {
+          float v[4] = {dacc[pt][0], dacc[pt][1], dacc[pt][2], dacc[pt][3]};
+          dstore4<bf16_t>(drow + (16 * pt + r) * 16, v, false);
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     u = un; q = qn;
@@ -217,12 +269,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
   for (int i = t; i < WSIZE / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(img)[i];
 }
 
-template <int CA16, bool PRO_P, bool PRO_G>
+template <int CA16, bool PRO_P, bool PRO_G, bool DG, bool X2>
 static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
   constexpr int KS = 4, S = 2, WP = 32, CB16 = 1;
   constexpr int WL = S * (WP - 1) + KS;
-  constexpr size_t lds = 4 * (size_t)((KS + S) * WL * CB16 * 32 + WP * CA16 * 32);
-  auto kern = &wgrad_stream_kernel<KS, S, 1, WP, CA16, CB16, PRO_P, PRO_G>;
+  constexpr size_t lds = 4 * (size_t)((KS + S) * WL * CB16 * 32 + WP * CA16 * 32 + (X2 ? WP * 32 : 0));
+  auto kern = &wgrad_stream_kernel<KS, S, 1, WP, CA16, CB16, PRO_P, PRO_G, DG, X2>;
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -233,15 +285,20 @@ static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
   return check_launch("wgrad_stream");
 }
 
-// Returns 1 when the launch was taken (kernel + reduce enqueued), 0 when the shape is not this kernel's, <0 on error.  MMVAE_WSTREAM=0: off
-int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s) {
+static bool wstream_enabled() {
   static const int enabled = [] { const char* e = getenv("MMVAE_WSTREAM"); return e ? atoi(e) : 1; }();
-  if (!enabled || dt != DT_BF16 || a.P_planar || a.G_planar || !a.scratch) return 0;
-  if (a.ksz != 4 || a.stride != 2 || a.pad != 1 || a.ntaps != 16) return 0;
-  if (a.Wp != 32 || a.Wg != 64 || a.Hg != 2 * a.Hp || a.Cb != 16 || (a.Ca != 16 && a.Ca != 32)) return 0;
-  if (a.Cb_valid != a.Cb || a.Ca_valid != a.Ca) return 0;
-  for (int t = 0; t < 16; ++t) if (a.tap_off[t] != t) return 0;
-  WStreamArgs b; memset(&b, 0, sizeof(b));
+  return enabled != 0;
+}
+static bool wstream_shape(int dt, const WgradArgs& a) {
+  if (!wstream_enabled() || dt != DT_BF16 || a.P_planar || a.G_planar || !a.scratch) return false;
+  if (a.ksz != 4 || a.stride != 2 || a.pad != 1 || a.ntaps != 16) return false;
+  if (a.Wp != 32 || a.Wg != 64 || a.Hg != 2 * a.Hp || a.Cb != 16 || (a.Ca != 16 && a.Ca != 32)) return false;
+  if (a.Cb_valid != a.Cb || a.Ca_valid != a.Ca) return false;
+  for (int t = 0; t < 16; ++t) if (a.tap_off[t] != t) return false;
+  return true;
+}
+static int wstream_fill(const WgradArgs& a, WStreamArgs& b) {
+  memset(&b, 0, sizeof(b));
   b.P = a.P; b.G = a.G; b.part = a.scratch;
   b.proP_scale = a.proP_scale; b.proP_shift = a.proP_shift; b.proP_relu = a.proP_relu;
   b.proG_scale = a.proG_scale; b.proG_shift = a.proG_shift; b.proG_relu = a.proG_relu;
@@ -252,18 +309,52 @@ int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s) {
   while (gx > 8 && (long)gx * 4 > b.nunits) gx -= 8;
   const int wsize = 16 * a.Ca * a.Cb;
   if ((size_t)gx * wsize * 4 > kWgradScratchBytes) return 0;
-  const bool pp = a.proP_scale != nullptr, pg = a.proG_scale != nullptr;
-  int rc;
-  if (a.Ca == 16) rc = pp ? (pg ? launch_wstream_t<1, true, true>(b, gx, s) : launch_wstream_t<1, true, false>(b, gx, s))
-                          : (pg ? launch_wstream_t<1, false, true>(b, gx, s) : launch_wstream_t<1, false, false>(b, gx, s));
-  else rc = pp ? (pg ? launch_wstream_t<2, true, true>(b, gx, s) : launch_wstream_t<2, true, false>(b, gx, s))
-               : (pg ? launch_wstream_t<2, false, true>(b, gx, s) : launch_wstream_t<2, false, false>(b, gx, s));
-  if (rc < 0) return rc;
+  return gx;
+}
+static int wstream_reduce(const WgradArgs& a, int gx, hipStream_t s) {
   WgradReduceArgs u; memset(&u, 0, sizeof(u));
   u.part = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.nparts = gx;
   u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid; u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
   for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
-  const int rc2 = launch_wgrad_reduce(u, s);
+  return launch_wgrad_reduce(u, s);
+}
+
+// Returns 1 when the launch was taken (kernel + reduce enqueued), 0 when the shape is not this kernel's, <0 on error.  MMVAE_WSTREAM=0: off
+int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s) {
+  if (!wstream_shape(dt, a)) return 0;
+  WStreamArgs b;
+  const int gx = wstream_fill(a, b);
+  if (gx <= 0) return 0;
+  const bool pp = a.proP_scale != nullptr, pg = a.proG_scale != nullptr;
+  int rc;
+  if (a.Ca == 16) rc = pp ? (pg ? launch_wstream_t<1, true, true, false, false>(b, gx, s) : launch_wstream_t<1, true, false, false, false>(b, gx, s))
+                          : (pg ? launch_wstream_t<1, false, true, false, false>(b, gx, s) : launch_wstream_t<1, false, false, false, false>(b, gx, s));
+  else rc = pp ? (pg ? launch_wstream_t<2, true, true, false, false>(b, gx, s) : launch_wstream_t<2, true, false, false, false>(b, gx, s))
+               : (pg ? launch_wstream_t<2, false, true, false, false>(b, gx, s) : launch_wstream_t<2, false, false, false, false>(b, gx, s));
+  if (rc < 0) return rc;
+  const int rc2 = wstream_reduce(a, gx, s);
+  return rc2 < 0 ? rc2 : 1;
+}
+
+// Weight gradient AND data gradient (w.r.t. P) of a 16 -> 16 channel k4 s2 layer in one pass over G (MMVAE_WSTREAM_DG=0: off).
+//   wd: the conv's packed down form [Ca][16][Cb]; dx [N][Hp][32][16]; x2 / w2 (optional): the 1x1 shortcut's operand on the P grid and its
+//   packed [Ca][16] matrix.  Returns 1 when taken, 0 when the shape is not this kernel's, <0 on error.
+bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a) {
+  static const int enabled = [] { const char* e = getenv("MMVAE_WSTREAM_DG"); return e ? atoi(e) : 1; }();
+  return enabled != 0 && wstream_shape(dt, a) && a.Ca == 16 && !a.proG_scale;
+}
+int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, hipStream_t s) {
+  if (!dgrad_wgrad_stream_shape(dt, a) || !wd || !dx || ((x2 != nullptr) != (w2 != nullptr))) return 0;
+  WStreamArgs b;
+  const int gx = wstream_fill(a, b);
+  if (gx <= 0) return 0;
+  b.wd = wd; b.dx = dx; b.x2 = x2; b.w2 = w2;
+  const bool pp = a.proP_scale != nullptr;
+  int rc;
+  if (x2) rc = pp ? launch_wstream_t<1, true, false, true, true>(b, gx, s) : launch_wstream_t<1, false, false, true, true>(b, gx, s);
+  else rc = pp ? launch_wstream_t<1, true, false, true, false>(b, gx, s) : launch_wstream_t<1, false, false, true, false>(b, gx, s);
+  if (rc < 0) return rc;
+  const int rc2 = wstream_reduce(a, gx, s);
   return rc2 < 0 ? rc2 : 1;
 }
 

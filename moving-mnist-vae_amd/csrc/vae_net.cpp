@@ -178,6 +178,7 @@ const Plan& Net::plan(int N) {
   P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
   P.wscratch = take((long)kWgradScratchBytes);
+  P.wscratch2 = take(512L * 16 * 16 * 16 * 4);        // partial images of a fused dgrad+wgrad pass on the caller's stream (512 blocks x [16][16][16] f32)
   P.stem_R = take(1024 * 8);
   P.stem_gram = take(1024L * stem_bwd_part_floats() * 4);
   P.bytes = (size_t)cur;
@@ -892,6 +893,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                  ssc, ssh));
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
+    bool fuse_c2 = false, fuse_cs = false;
     if (B.identity) {
       // conv2 (3x3 Conv2d): wgrad(P = dy2, G = a1 with BN+ReLU prologue); dgrad -> d_a1
       MM_TRY(run_wgrad(B.c2, N, base + P.dy2[ds], B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3),
@@ -899,10 +901,22 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       MM_TRY(run_up(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
     } else {
       // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
-      MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2[ds], B.Hout, B.Wout, nullptr,
-                       nullptr, grads, wsm));
-      MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
-      MM_TRY(run_down(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
+      // Where the shape allows (uplayer5: 16 -> 16 channels, 32x32 -> 64x64, bf16) dgrad and wgrad of a ConvT are ONE pass over its dy
+      // tensor on the caller's stream (wgrad_stream_kernel with DG): dy2 / dys (671 MB each at N = 5120) are read once instead of twice.
+      fuse_c2 = !B.c2.fp8 && op_bwd_fusable(dt(), geom(B.c2), N, B.Hin, B.Win, B.Hout, B.Wout);
+      fuse_cs = !B.cs.fp8 && op_bwd_fusable(dt(), geom(B.cs), N, B.Hin, B.Win, B.Hout, B.Wout) && B.C == 16;
+      float* wsc2 = reinterpret_cast<float*>(base + P.wscratch2);
+      if (!fuse_c2)
+        MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2[ds], B.Hout, B.Wout, nullptr,
+                         nullptr, grads, wsm));
+      if (!fuse_cs) MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
+      if (fuse_c2) {
+        const int rcf = op_run_bwd_fused(dt(), geom(B.c2), N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, base + P.dy2[ds],
+                                         B.Hout, B.Wout, base + plan_.packed + B.c2.packD * (long)esz(), base + P.da1, nullptr, nullptr,
+                                         grads + B.c2.off, s, wsc2, B.c2.wscale);
+        if (rcf <= 0) { if (rcf == 0) set_error("decoder_bwd: fused backward of %s not taken", "conv2"); return rcf < 0 ? rcf : MMVAE_ERR_UNSUPPORTED; }
+      } else
+        MM_TRY(run_down(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
     }
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
     MM_TRY(np);
@@ -916,7 +930,13 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(side_mark(i));
     if (B.identity)     // d_xin already holds the shortcut's share: the 1x1 conv's data gradient is added to it
       MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
-    else                // one kernel: the 1x1 conv's data gradient (dy1, already on this block's input grid) is a second source of the shortcut's
+    else if (fuse_cs) {  // shortcut ConvT: weight gradient + data gradient + the 1x1 conv's share (dy1 (x) w1), one pass over dys
+      const int rcf = op_run_bwd_fused(dt(), geom(B.cs), N, xin, B.Hin, B.Win, xs, xb, 1, base + P.dys[ds], B.Hout, B.Wout,
+                                       base + plan_.packed + B.cs.packD * (long)esz(), base + P.g[cur ^ 1], base + P.dy1[ds],
+                                       base + plan_.packed + B.c1.packU * (long)esz(), grads + B.cs.off, s,
+                                       reinterpret_cast<float*>(base + P.wscratch2), B.cs.wscale);
+      if (rcf <= 0) { if (rcf == 0) set_error("decoder_bwd: fused backward of %s not taken", "upsample"); return rcf < 0 ? rcf : MMVAE_ERR_UNSUPPORTED; }
+    } else              // one kernel: the 1x1 conv's data gradient (dy1, already on this block's input grid) is a second source of the shortcut's
       MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s,
                       &B.c1, base + P.dy1[ds]));
     cur ^= 1;

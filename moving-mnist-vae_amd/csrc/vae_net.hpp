@@ -48,6 +48,7 @@ struct Plan {
   long g[2], dy1[2], dy2[2], dys[2], da1, dh;            // backward temporaries (dy*: two sets, alternating per block, so the
                                                          // weight gradients on the side stream may lag one block behind)
   long wscratch;                                         // [tap][a][b] reduction image of the largest weight gradient
+  long wscratch2;                                        // partial images of the fused dgrad+wgrad passes (caller's stream)
   long stem_R, stem_gram;
   long cvec;                                             // constants: 256 ones, 256 zeros (identity shortcuts as a unit BatchNorm)
   long act0d;                                            // blocks > 1: relu(bn(decoder stem)) materialised (an identity shortcut needs it)                                // stem backward: patch gram matrix (1024 doubles) and its per-block partials
