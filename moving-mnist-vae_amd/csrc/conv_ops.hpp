@@ -38,10 +38,12 @@ int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws
 // Weight gradient AND the data gradient w.r.t. the small-side tensor P in ONE pass over G (wgrad_stream_kernel with DG; the 16 -> 16
 // channel k4 s2 layers on 32x32 -> 64x64 maps, bf16):  dW += P^T (x) G;  dP = down(G) with the conv's packed down form (+ x2 (x) w2,
 // the 1x1 shortcut's share, x2 on P's grid with 16 channels, w2 its packed up form).  Returns 1 when taken, 0 when the shape is not
-// that kernel's (callers then run op_run_down + op_run_wgrad), <0 on error.  scratch: kWgradScratchBytes, not shared with a concurrent wgrad.
+// that kernel's (callers then run op_run_down + op_run_wgrad), <0 on error.  bn_part (optional; P prologue'd, no x2): the pass also
+// leaves the BatchNorm-backward partial sums of P's BatchNorm, rows [return value][2][16] -- the layout launch_bn_bwd_reduce writes.
+// Taken: returns the number of rows (> 0).  scratch: kWgradScratchBytes, not shared with a concurrent wgrad.
 bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl);
 int op_run_bwd_fused(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                      const void* G, int Hl, int Wl, const void* packed_down, void* dP, const void* x2, const void* w2_packed, float* dW,
-                     hipStream_t s, float* scratch, float scale = 1.f);
+                     hipStream_t s, float* scratch, float scale = 1.f, float* bn_part = nullptr);
 
 }  // namespace mmvae

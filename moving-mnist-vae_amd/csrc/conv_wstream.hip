@@ -32,6 +32,8 @@ struct WStreamArgs {
   const void* wd;            // packed [Ca][KS*KS][Cb] of T (the conv's "down" form)
   void* dx;                  // [N][Hp][WP][Ca] of T
   const void* x2; const void* w2;   // optional second source on the P grid: x2 [N][Hp][WP][16], w2 packed [Ca][16]
+  // BatchNorm-backward partial sums of the BN that produced P (DG + PRO_P): g = dx * (P*scale+shift > 0); rows [block][2][16]: sum g, sum g * P
+  float* bn_part;
 };
 
 // KS x KS taps, stride S, padding PAD; WP = P row width (32: one row per MFMA K-step); CA16, CB16: channel tiles of P and G
@@ -39,8 +41,12 @@ struct WStreamArgs {
 // its data gradient needs): the dy tensor is read ONCE for both.  Two taps (2 x 16 G channels) make one 16x16x32 MFMA K-step; the A
 // operand is the conv's packed "down" weights (8 fragments, loaded once), B fragments are plain 16-byte reads of ring pixels.
 // X2 (with DG): + the 1x1 shortcut's share, x2 (x) w2, from a second row staged per step (the block-input gradient in one kernel).
-template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2>
+// ST (with DG and PRO_P): P is a pre-BatchNorm tensor whose BN+ReLU is the prologue; the pass also reduces that BatchNorm's backward sums
+// (sum g, sum g*P over all pixels, g = dx masked by the ReLU) from the data gradient it has just computed -- the bn_bwd_reduce launch
+// that would re-read dx and P disappears.
+template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST>
 __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
+  static_assert(!ST || (DG && PRO_P && !X2), "BatchNorm sums ride on the data gradient of a prologue'd P");
   static_assert(WP == 32, "one P row per K-step");
   static_assert(!DG || (CA16 == 1 && CB16 == 1 && KS == 4), "fused data gradient: 16 -> 16 channels, 4x4 taps");
   static_assert(!X2 || DG, "the second source rides on the data gradient");
@@ -50,15 +56,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
   constexpr int NSLOT = KS + S;                            // ring: the KS rows being multiplied + the S rows arriving
   constexpr int PB = WP * CAB;                             // bytes of a P row
   constexpr int X2B = X2 ? WP * 32 : 0;                    // bytes of an x2 row (16 channels)
-  constexpr int WAVE_LDS = NSLOT * ROWB + PB + X2B;
+  constexpr int RAWB = ST ? PB : 0;                        // raw copy of the P row (before the prologue) for the BatchNorm sums
+  constexpr int WAVE_LDS = NSLOT * ROWB + PB + X2B + RAWB;
   constexpr int NT = KS * KS;
   constexpr int WSIZE = NT * CA16 * 16 * CB16 * 16;        // floats of a partial image
-  static_assert(4 * WAVE_LDS >= WSIZE * 4, "the flush image aliases the rings");
+  static_assert(4 * WAVE_LDS >= WSIZE * 4 + 512, "the flush image (+ 128 floats of BatchNorm sums) aliases the rings");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
   char* ring = smem + wv * WAVE_LDS;
   char* prow = ring + NSLOT * ROWB;
   char* x2row = prow + PB;
+  char* rawrow = x2row + X2B;
   constexpr int Wg = S * WP;                               // G row width (the launcher checks it)
   constexpr int grow_bytes = Wg * CBB;                     // bytes of a G row in memory
   constexpr int GV = (S * grow_bytes + 1023) / 1024;       // 16-byte vectors per lane for the S rows of a step
@@ -101,6 +109,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
 #pragma unroll
       for (int cb = 0; cb < CB16; ++cb) acc[k][ca][cb] = (f32x4){0, 0, 0, 0};
 
+  float bsc[4] = {0, 0, 0, 0}, bsh[4] = {0, 0, 0, 0}, bs0[4] = {0, 0, 0, 0}, bs1[4] = {0, 0, 0, 0};
+  if constexpr (ST) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bsc[j] = a.proP_scale[4 * gq + j]; bsh[j] = a.proP_shift[4 * gq + j]; }
+  }
   Vec16 wdA[DG ? KS * KS / 2 : 1], w2A = Vec16{{0, 0, 0, 0}};
   if constexpr (DG) {
     // A[row a = r][k = 8gq ..]: taps (kh, 2kp) and (kh, 2kp + 1), 16 G channels each = 64 contiguous bytes of wd[a][tap][b]
@@ -169,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
 #pragma unroll
       for (int k = 0; k < PV; ++k) {
         Vec16 v = pv[k];
+        if constexpr (ST) *reinterpret_cast<Vec16*>(rawrow + (lane + 64 * k) * 16) = v;
         if (PRO_P) {
           float f[8];
           Elem<bf16_t>::unpack(v, f);
@@ -233,6 +247,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
             dacc[pt] = mma_bf16(w2A, b, dacc[pt]);
           }
         }
+        if constexpr (ST) {
+#pragma unroll
+          for (int pt = 0; pt < WP / 16; ++pt) {
+            const uint2 yr = *reinterpret_cast<const uint2*>(rawrow + (16 * pt + r) * CAB + gq * 8);      // P[pixel][4gq .. 4gq+3]
+            const float y[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u), __uint_as_float(yr.y << 16), __uint_as_float(yr.y & 0xffff0000u)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = (y[j] * bsc[j] + bsh[j] > 0.f) ? dacc[pt][j] : 0.f;
+              bs0[j] += g; bs1[j] += g * y[j];
+            }
+          }
+        }
         bf16_t* drow = reinterpret_cast<bf16_t*>(a.dx) + (((long)n * a.Hp + (h0 + q - 1)) * WP) * 16 + 4 * gq;
 #pragma unroll
         for (int pt = 0; pt < WP / 16; ++pt) {
@@ -265,16 +291,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
     }
     __syncthreads();
   }
+  if constexpr (ST) {
+    // per-channel sums: the 16 pixel-lanes of a row (DPP), then the four waves in order through LDS (behind the partial image)
+    float* sb = img + WSIZE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bs0[j] = row16_sum(bs0[j]); bs1[j] = row16_sum(bs1[j]); }
+    if (r == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sb[wv * 32 + 4 * gq + j] = bs0[j]; sb[wv * 32 + 16 + 4 * gq + j] = bs1[j]; }
+    }
+    __syncthreads();
+    if (t < 32) a.bn_part[(long)blockIdx.x * 32 + t] = (sb[t] + sb[32 + t]) + (sb[64 + t] + sb[96 + t]);
+  }
   float* dst = a.part + (long)blockIdx.x * WSIZE;
   for (int i = t; i < WSIZE / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(img)[i];
 }
 
-template <int CA16, bool PRO_P, bool PRO_G, bool DG, bool X2>
+template <int CA16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST = false>
 static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
   constexpr int KS = 4, S = 2, WP = 32, CB16 = 1;
   constexpr int WL = S * (WP - 1) + KS;
-  constexpr size_t lds = 4 * (size_t)((KS + S) * WL * CB16 * 32 + WP * CA16 * 32 + (X2 ? WP * 32 : 0));
-  auto kern = &wgrad_stream_kernel<KS, S, 1, WP, CA16, CB16, PRO_P, PRO_G, DG, X2>;
+  constexpr size_t lds = 4 * (size_t)((KS + S) * WL * CB16 * 32 + WP * CA16 * 32 + (X2 ? WP * 32 : 0) + (ST ? WP * CA16 * 32 : 0));
+  auto kern = &wgrad_stream_kernel<KS, S, 1, WP, CA16, CB16, PRO_P, PRO_G, DG, X2, ST>;
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -338,24 +376,27 @@ int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s) {
 
 // Weight gradient AND data gradient (w.r.t. P) of a 16 -> 16 channel k4 s2 layer in one pass over G (MMVAE_WSTREAM_DG=0: off).
 //   wd: the conv's packed down form [Ca][16][Cb]; dx [N][Hp][32][16]; x2 / w2 (optional): the 1x1 shortcut's operand on the P grid and its
-//   packed [Ca][16] matrix.  Returns 1 when taken, 0 when the shape is not this kernel's, <0 on error.
+//   packed [Ca][16] matrix; bn_part (optional, needs the prologue and no x2): [blocks][2][16] BatchNorm-backward sums of P's BatchNorm.
+//   Returns the number of blocks (> 0) when taken, 0 when the shape is not this kernel's, <0 on error.
 bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a) {
   static const int enabled = [] { const char* e = getenv("MMVAE_WSTREAM_DG"); return e ? atoi(e) : 1; }();
   return enabled != 0 && wstream_shape(dt, a) && a.Ca == 16 && !a.proG_scale;
 }
-int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, hipStream_t s) {
+int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s) {
   if (!dgrad_wgrad_stream_shape(dt, a) || !wd || !dx || ((x2 != nullptr) != (w2 != nullptr))) return 0;
+  if (bn_part && (x2 || !a.proP_scale)) { set_error("dgrad_wgrad_stream: BatchNorm sums need the prologue'd P and no second source"); return MMVAE_ERR_ARG; }
   WStreamArgs b;
   const int gx = wstream_fill(a, b);
   if (gx <= 0) return 0;
-  b.wd = wd; b.dx = dx; b.x2 = x2; b.w2 = w2;
+  b.wd = wd; b.dx = dx; b.x2 = x2; b.w2 = w2; b.bn_part = bn_part;
   const bool pp = a.proP_scale != nullptr;
   int rc;
   if (x2) rc = pp ? launch_wstream_t<1, true, false, true, true>(b, gx, s) : launch_wstream_t<1, false, false, true, true>(b, gx, s);
+  else if (bn_part) rc = launch_wstream_t<1, true, false, true, false, true>(b, gx, s);
   else rc = pp ? launch_wstream_t<1, true, false, true, false>(b, gx, s) : launch_wstream_t<1, false, false, true, false>(b, gx, s);
   if (rc < 0) return rc;
   const int rc2 = wstream_reduce(a, gx, s);
-  return rc2 < 0 ? rc2 : 1;
+  return rc2 < 0 ? rc2 : gx;             // taken: the number of blocks = rows of bn_part
 }
 
 }  // namespace mmvae

@@ -68,7 +68,7 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
 int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s);   // conv_wstream.hip: 1 = taken, 0 = not this kernel's shape, <0 error
 // weight gradient + data gradient (w.r.t. P) of a 16 -> 16 channel k4 s2 layer in one pass over G (conv_wstream.hip)
 bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a);
-int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, hipStream_t s);
+int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s);
 
 // ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
 // A tile is up to TP (128, or 64/32 for wgrad on tiny feature maps) q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.

@@ -894,6 +894,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
     bool fuse_c2 = false, fuse_cs = false;
+    int np_b1 = 0;                       // rows of bn1's backward sums when the fused pass has left them in `part`
     if (B.identity) {
       // conv2 (3x3 Conv2d): wgrad(P = dy2, G = a1 with BN+ReLU prologue); dgrad -> d_a1
       MM_TRY(run_wgrad(B.c2, N, base + P.dy2[ds], B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3),
@@ -911,14 +912,16 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                          nullptr, grads, wsm));
       if (!fuse_cs) MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
       if (fuse_c2) {
+        // ... and bn1's backward sums come out of the same pass (the data gradient is in registers, y1 is the pass's P operand)
         const int rcf = op_run_bwd_fused(dt(), geom(B.c2), N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, base + P.dy2[ds],
                                          B.Hout, B.Wout, base + plan_.packed + B.c2.packD * (long)esz(), base + P.da1, nullptr, nullptr,
-                                         grads + B.c2.off, s, wsc2, B.c2.wscale);
+                                         grads + B.c2.off, s, wsc2, B.c2.wscale, B.C == 16 ? part : nullptr);
         if (rcf <= 0) { if (rcf == 0) set_error("decoder_bwd: fused backward of %s not taken", "conv2"); return rcf < 0 ? rcf : MMVAE_ERR_UNSUPPORTED; }
+        if (B.C == 16) np_b1 = rcf;
       } else
         MM_TRY(run_down(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s));
     }
-    np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
+    np = np_b1 > 0 ? np_b1 : launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npi, B.C, part, s);
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, (double)npi, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),
