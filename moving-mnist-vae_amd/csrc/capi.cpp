@@ -296,6 +296,7 @@ int mmvae_batchnorm_bwd(int dt, const void* dout, const void* y, const void* out
 }
 int mmvae_stem_fwd(int dt, const void* x, const float* w, void* y, int N, int Sz, float* stats, void* scratch, void* st) {
   if (!scratch || N < 1 || Sz < 9 || Sz > 64) { set_error("stem_fwd: bad arguments"); return MMVAE_ERR_ARG; }
+  if (stem_fwd_stream_ok(dt, Sz)) return launch_stem_fwd_stream(dt, x, w, y, stats, N, Sz, S(st));
   const int H1 = (Sz + 4 - 5) / 2 + 1;
   const int cpad = dt == DT_F32 ? 4 : 8;
   PackArgs pa; std::memset(&pa, 0, sizeof(pa));

@@ -194,6 +194,9 @@ int launch_tail_wgrad(int dt, const void* x, const float* dy, float* dW, float* 
 
 // stem backward in one pass (stem_bwd.hip): BatchNorm sums + the three pixel reductions dW is an affine function of
 bool stem_bwd_fusable(int S);
+// stem forward as a per-wave stream (bf16; stem_bwd.hip): returns stats rows (> 0) or an error
+bool stem_fwd_stream_ok(int dt, int S);
+int launch_stem_fwd_stream(int dt, const void* x, const float* w, void* y, float* stats, int N, int S, hipStream_t s);
 int stem_bwd_part_floats();
 int launch_stem_gram(int dt, const void* x, float* scratch, long scratch_cap_floats, double* R, int N, int S, int Ho, int Wo, hipStream_t s);
 int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* ms, const float* mb, float* partials,

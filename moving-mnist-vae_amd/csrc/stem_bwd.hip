@@ -323,6 +323,121 @@ static size_t stem_lds(const StemBwdArgs& a, int dt) {
   return lds > (size_t)kStemPartFloats * 4 ? lds : (size_t)kStemPartFloats * 4;
 }
 
+// ---------------------------------------------------------------- stem forward as the same kind of stream (bf16 storage)
+// encoder.conv1 (1 -> 32, k5 s2 p2) is 25 multiply-adds per output: the patch-tile kernel stages the 1-channel image as 8 padded
+// channels and moves the layer at 1.6 TB/s (212 us at N = 5120).  Here every wave walks its own 32-pixel slabs: image rows in a
+// wave-private f32 LDS patch (loaded once, next slab in flight), the B fragment of a pixel tile = its 25 taps gathered from that patch
+// (7 zero taps pad K to 32: ONE v_mfma_f32_16x16x32_bf16 per 16 pixels x 16 channels), A = the weights, built once from the f32
+// master (no packing launch), a lane ends with 8 consecutive channels of a pixel = one 16-byte store; BatchNorm sums from the f32
+// results, per-block partial rows in fixed order.
+struct StemFwdArgs {
+  const void* x; const float* w; void* y; float* stats;
+  int N, H, W, Ho, Wo, wshift, rps, slabs_per_img, nslabs, prow, pw;
+};
+
+__global__ __launch_bounds__(256, 4) void stem_fwd_stream_kernel(StemFwdArgs a) {
+  typedef bf16_t T;
+  constexpr int VE = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
+  const int wave_bytes = a.prow * a.pw * 4;
+  float* sX = reinterpret_cast<float*>(smem + 1024 + wv * wave_bytes);   // this wave's image patch [prow][pw] f32, 4 halo columns a side
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  for (int i = lane; i < a.prow * a.pw; i += 64) sX[i] = 0.f;            // the halo columns stay zero
+  // A fragments: row r of fragment m is channel 8*(r/4) + 4m + r%4 (a lane's 2 x 4 results are then 8 consecutive channels);
+  // k = taps 8gq .. 8gq+7 (taps >= 25 are zero)
+  Vec16 wA[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int c = 8 * (r >> 2) + 4 * m + (r & 3);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int tap = 8 * gq + j; f[j] = tap < 25 ? a.w[c * 25 + tap] : 0.f; }
+    wA[m] = Elem<bf16_t>::pack(f);
+  }
+  // B gather: this lane's 8 taps as patch offsets (or -1)
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const int tap = 8 * gq + j; toff[j] = tap < 25 ? (tap / 5) * a.pw + tap % 5 : -1; }
+  auto pix_off = [&](int q) { return ((q >> a.wshift) * 2) * a.pw + (q & (a.Wo - 1)) * 2 + 2; };   // tap (0,0) of slab pixel q
+  const int po[2] = {pix_off(r), pix_off(16 + r)};
+  const int xvr = a.W / VE;
+  const int idx = lane;
+  const int xrow = idx < a.prow * xvr ? idx / xvr : (1 << 28), xcol = (idx % xvr) * VE;
+  float st1[8], st2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st1[j] = 0.f; st2[j] = 0.f; }
+  Vec16 xv = Vec16{{0, 0, 0, 0}};
+  auto issue = [&](int slab) {
+    const int n = slab / a.slabs_per_img, h0 = (slab - n * a.slabs_per_img) * a.rps;
+    const int r0 = 2 * h0 - 2;
+    xv = Vec16{{0, 0, 0, 0}};
+    if ((unsigned)(r0 + xrow) < (unsigned)a.H) xv = *reinterpret_cast<const Vec16*>(X + (((long)n * a.H + r0 + xrow) * a.W + xcol));
+  };
+  const int gw = blockIdx.x * 4 + wv, gstride = gridDim.x * 4;
+  int slab = gw;
+  if (slab < a.nslabs) issue(slab);
+  for (; slab < a.nslabs; slab += gstride) {
+    if (xrow < (1 << 28)) {
+      float f[VE];
+      Elem<T>::unpack(xv, f);
+      float* d = sX + xrow * a.pw + 4 + xcol;
+      *reinterpret_cast<float4*>(d) = make_float4(f[0], f[1], f[2], f[3]);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    if (slab + gstride < a.nslabs) issue(slab + gstride);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16_t* yrow = reinterpret_cast<bf16_t*>(a.y) + ((long)slab * 32) * 32 + 8 * gq;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = toff[j] >= 0 ? sX[po[pt] + toff[j]] : 0.f;
+      const Vec16 bf = Elem<bf16_t>::pack(f);
+      const f32x4 z = (f32x4){0, 0, 0, 0};
+      const f32x4 d0 = mma_bf16(wA[0], bf, z), d1 = mma_bf16(wA[1], bf, z);
+      const float v[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { st1[j] += v[j]; st2[j] += v[j] * v[j]; }
+      dstore8<bf16_t>(yrow + (16 * pt + r) * 32, v, false);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- BatchNorm sums: the 16 pixel-lanes of a row (DPP), then the four waves in order; one partial row [2][32] per block
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st1[j] = row16_sum(st1[j]); st2[j] = row16_sum(st2[j]); }
+  float* sb = reinterpret_cast<float*>(smem);                            // [4 waves][64]
+  if (r == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sb[wv * 64 + 8 * gq + j] = st1[j]; sb[wv * 64 + 32 + 8 * gq + j] = st2[j]; }
+  }
+  __syncthreads();
+  if (a.stats && t < 64) a.stats[(long)blockIdx.x * 64 + t] = (sb[t] + sb[64 + t]) + (sb[128 + t] + sb[192 + t]);
+}
+
+bool stem_fwd_stream_ok(int dt, int S) {
+  static const bool env = [] { const char* e = getenv("MMVAE_STEM_FWD_STREAM"); return !(e && e[0] == '0'); }();
+  return env && dt == DT_BF16 && stem_bwd_fusable(S);
+}
+// y [N][S/2][S/2][32] bf16 = conv1(x), stats (nullable): partial rows [rows][2][32]; returns rows (> 0) or an error
+int launch_stem_fwd_stream(int dt, const void* x, const float* w, void* y, float* stats, int N, int S, hipStream_t s) {
+  if (!stem_fwd_stream_ok(dt, S)) { set_error("stem_fwd_stream: bf16, image size 64 / 32 / 16"); return MMVAE_ERR_UNSUPPORTED; }
+  StemBwdArgs g; memset(&g, 0, sizeof(g));
+  const int Ho = S / 2;
+  const int rc0 = stem_geom(g, dt, N, S, Ho, Ho);
+  if (rc0 < 0) return rc0;
+  StemFwdArgs a; memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.y = y; a.stats = stats;
+  a.N = N; a.H = S; a.W = S; a.Ho = Ho; a.Wo = Ho; a.wshift = g.wshift; a.rps = g.rps; a.slabs_per_img = g.slabs_per_img; a.nslabs = g.nslabs;
+  a.prow = g.prow; a.pw = g.pw;
+  int gx = 1024;
+  if (gx * 4 > a.nslabs) gx = (a.nslabs + 3) / 4;
+  const size_t lds = 1024 + 4 * (size_t)a.prow * a.pw * 4;
+  hipLaunchKernelGGL(stem_fwd_stream_kernel, dim3(gx), dim3(256), lds, s, a);
+  const int rc = check_launch("stem_fwd_stream");
+  return rc ? rc : gx;
+}
+
 // Patch gram matrix of the batch (input only): scratch = rows * stem_bwd_part_floats() floats, R = 1024 doubles.
 int launch_stem_gram(int dt, const void* x, float* scratch, long scratch_cap_floats, double* R, int N, int S, int Ho, int Wo, hipStream_t s) {
   StemBwdArgs a; memset(&a, 0, sizeof(a));

@@ -462,7 +462,11 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   MM_TRY(pack_batch_flush(dt(), s));
   MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
   static const bool stem_direct = [] { const char* e = getenv("MMVAE_STEM_DIRECT"); return e && e[0] == '1'; }();
-  if (stem_direct) {
+  if (!stem_direct && cfg.in_ch == 1 && stem_fwd_stream_ok(dt(), S)) {
+    const int np = launch_stem_fwd_stream(dt(), base + P.x_t, params + stem.off, base + P.y0, stats, N, S, s);
+    MM_TRY(np);
+    if (training) MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
+  } else if (stem_direct) {
     MM_TRY(launch_stem_fwd(dt(), base + P.x_t, params + stem.off, base + P.y0, N, S, S, H1, W1, 32, s));
     if (training) {
       const int np = launch_chan_stats_nhwc(dt(), base + P.y0, (long)N * H1 * W1, 32, part, s);
