@@ -211,6 +211,10 @@ int mmvae_conv2d_fwd(int dt, int transposed, const void* x, const float* w, void
   const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
   // weight == NULL: `scratch` still holds the packed weights of an earlier call with the same geometry (pack once, run many)
   SecondSrc q;
+  if (!transposed && conv3_stream_ok(dt, Cin, Cout, k, s, p, H, W)) {      // the first encoder block's 3x3 convs: per-wave stream
+    if (w) { int rc = op_pack_down(dt, g, w, scratch, S(st)); if (rc < 0) return rc; }
+    return launch_conv3_stream(dt, s, x, scratch, nullptr, y, nullptr, ps, pb, relu, stats, nullptr, N, Ho, S(st));
+  }
   if (!transposed) {
     q.wfrag = op_frag_down(dt, g, H, W);
     if (w) { int rc = op_pack_down(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc; }

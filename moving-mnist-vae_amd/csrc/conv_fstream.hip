@@ -1,0 +1,203 @@
+// conv3_stream_kernel: forward of the 32 -> 32 channel 3x3 convolutions of the first encoder block (encoder.layer1: conv1 stride 2 on
+// the 32x32 stem activation together with the block's 1x1 stride-2 shortcut, conv2 stride 1 on 16x16) as a barrier-free stream.
+//
+// The patch-tile kernel moves these layers at 1.5-2.2 TB/s, and conv1 and the shortcut each read the same 335 MB input (at N = 5120).
+// Here every WAVE walks strips of output rows on its own: a ring of input rows (fused BN+ReLU applied once, on the way in) lives in
+// wave-private LDS, the next rows are in flight in registers, one output row = 16 pixels = one MFMA column tile, so a 3x3 tap is ONE
+// v_mfma_f32_16x16x32_bf16 per 16 output channels (K = the 32 input channels), B fragments are plain 16-byte reads of ring pixels, the
+// A fragments (9 taps x 2, + 2 for the shortcut: the centre tap's pixel IS the shortcut's pixel) stay in registers for the whole
+// kernel, a lane ends with 8 consecutive output channels of its pixel (one 16-byte store per tensor), BatchNorm sums come from the
+// f32 results.  With SC the input is read ONCE for conv1 and the shortcut.
+#include <hip/hip_runtime.h>
+
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernels.hpp"
+#include "tile_common.hpp"
+
+namespace mmvae {
+
+struct Conv3StreamArgs {
+  const void* x; const void* w; const void* wsc; void* y; void* ysc;
+  const float* pro_scale; const float* pro_shift; int pro_relu;
+  float* stats; float* stats_sc;          // partial rows [blocks][2][32] (nullable)
+  int N, Ho, Hi;
+  int HS, nunits;                         // output rows per strip, N * Ho / HS
+};
+
+// S: stride (1 or 2); SC: also the 1x1 stride-S shortcut (second weight set, second output); 32 -> 32 channels, 16 output columns
+template <int S, bool SC, bool PRO>
+__global__ __launch_bounds__(256, 2) void conv3_stream_kernel(Conv3StreamArgs a) {
+  constexpr int KS = 3, PAD = 1, WO = 16, WI = S * WO, CB = 64;            // bytes per pixel (32 channels of bf16)
+  constexpr int WL = WI + 2;                                                // ring row: one zero pixel on each side
+  constexpr int ROWB = WL * CB;
+  constexpr int NSLOT = KS + S;
+  constexpr int WAVE_LDS = NSLOT * ROWB;
+  constexpr int RV = S * WI * CB / 1024;                                    // 16-byte vectors per lane for the S rows of a step (S = 2: 4, S = 1: 1)
+  constexpr int NPRIME = (KS - S + S - 1) / S;                              // steps that only load (S = 2: 1, S = 1: 2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
+  char* ring = smem + 2048 + wv * WAVE_LDS;
+  for (int s = 0; s < NSLOT; ++s) {
+    if (lane < 4) *reinterpret_cast<Vec16*>(ring + s * ROWB + lane * 16) = Vec16{{0, 0, 0, 0}};
+    else if (lane < 8) *reinterpret_cast<Vec16*>(ring + s * ROWB + (WL - 1) * CB + (lane - 4) * 16) = Vec16{{0, 0, 0, 0}};
+  }
+  // A fragments: row r of fragment m is output channel 8*(r/4) + 4m + r%4; k = input channels 8gq .. 8gq+7 of the tap: 16 bytes of
+  // the packed [cout][tap][cin] weights
+  Vec16 wA[KS * KS][2], wS[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int c = 8 * (r >> 2) + 4 * m + (r & 3);
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap)
+      wA[tap][m] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.w) + ((c * KS * KS + tap) * 32 + 8 * gq) * 2);
+    wS[m] = SC ? *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.wsc) + (c * 32 + 8 * gq) * 2) : Vec16{{0, 0, 0, 0}};
+  }
+  float psc[8], psh[8];
+  if (PRO) {
+    const int c = (lane & 3) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { psc[j] = a.pro_scale[c + j]; psh[j] = a.pro_shift[c + j]; }
+  }
+  const float lo = a.pro_relu ? 0.f : -__builtin_inff();
+  float st[SC ? 4 : 2][8];
+#pragma unroll
+  for (int q = 0; q < (SC ? 4 : 2); ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st[q][j] = 0.f;
+
+  const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(a.x);
+  const int nblk = gridDim.x;
+  int u_first, u_step, u_end;
+  if ((nblk & 7) == 0) {                                                    // XCD-aware walk (see conv_wstream.hip)
+    const int per = (a.nunits + 7) >> 3;
+    const int lo_u = (blockIdx.x & 7) * per;
+    u_first = lo_u + (blockIdx.x >> 3) * 4 + wv; u_step = (nblk >> 3) * 4; u_end = min(a.nunits, lo_u + per);
+  } else { u_first = blockIdx.x * 4 + wv; u_step = nblk * 4; u_end = a.nunits; }
+  const int nstrips = a.Ho / a.HS;
+  const int nq = a.HS + NPRIME;
+
+  Vec16 xv[RV];
+  auto issue = [&](int u, int q) {
+    const int n = u / nstrips, oh0 = (u - n * nstrips) * a.HS;
+    const int top = S * (oh0 + q - NPRIME) + 1;                             // last input row of output row oh0 + q - NPRIME
+#pragma unroll
+    for (int k = 0; k < RV; ++k) {
+      const int byte = (lane + 64 * k) * 16;
+      const int rr = byte / (WI * CB), off = byte - rr * (WI * CB);
+      const int row = top - S + 1 + rr;
+      xv[k] = Vec16{{0, 0, 0, 0}};
+      if (row >= 0 && row < a.Hi) xv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(X) + (((long)n * a.Hi + row) * WI) * CB + off);
+    }
+  };
+  auto commit = [&](int u, int q) {
+    const int n = u / nstrips, oh0 = (u - n * nstrips) * a.HS;
+    const int top = S * (oh0 + q - NPRIME) + 1;
+#pragma unroll
+    for (int k = 0; k < RV; ++k) {
+      const int byte = (lane + 64 * k) * 16;
+      const int rr = byte / (WI * CB), off = byte - rr * (WI * CB);
+      const int row = top - S + 1 + rr;
+      Vec16 v = xv[k];
+      if (PRO && row >= 0 && row < a.Hi) {
+        float f[8];
+        Elem<bf16_t>::unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * psc[j] + psh[j], lo);
+        v = Elem<bf16_t>::pack(f);
+      }
+      *reinterpret_cast<Vec16*>(ring + ((row + 4 * NSLOT) % NSLOT) * ROWB + CB + off) = v;
+    }
+    (void)n;
+  };
+
+  int u = u_first, q = 0;
+  if (u < u_end) issue(u, 0);
+  while (u < u_end) {
+    commit(u, q);
+    int un = u, qn = q + 1;
+    if (qn == nq) { un = u + u_step; qn = 0; }
+    if (un < u_end) issue(un, qn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q >= NPRIME) {
+      const int n = u / nstrips, oh = (u - n * nstrips) * a.HS + q - NPRIME;
+      const int first = S * oh - PAD;
+      f32x4 acc[2], asc[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) { acc[m] = (f32x4){0, 0, 0, 0}; asc[m] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+        const char* rowp = ring + ((first + kh + 4 * NSLOT) % NSLOT) * ROWB;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const Vec16 b = *reinterpret_cast<const Vec16*>(rowp + (S * r + kw) * CB + gq * 16);
+          acc[0] = mma_bf16(wA[kh * KS + kw][0], b, acc[0]);
+          acc[1] = mma_bf16(wA[kh * KS + kw][1], b, acc[1]);
+          if (SC && kh == 1 && kw == 1) { asc[0] = mma_bf16(wS[0], b, asc[0]); asc[1] = mma_bf16(wS[1], b, asc[1]); }
+        }
+      }
+      const long po = (((long)n * a.Ho + oh) * WO + r) * 32 + 8 * gq;
+      {
+        const float v[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { st[0][j] += v[j]; st[1][j] += v[j] * v[j]; }
+        dstore8<bf16_t>(reinterpret_cast<bf16_t*>(a.y) + po, v, false);
+      }
+      if constexpr (SC) {
+        const float v[8] = {asc[0][0], asc[0][1], asc[0][2], asc[0][3], asc[1][0], asc[1][1], asc[1][2], asc[1][3]};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { st[2][j] += v[j]; st[3][j] += v[j] * v[j]; }
+        dstore8<bf16_t>(reinterpret_cast<bf16_t*>(a.ysc) + po, v, false);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u = un; q = qn;
+  }
+  // ---- BatchNorm sums: the 16 pixel-lanes of a row (DPP), the four waves in order; partial rows [2][32] per block and tensor
+  float* sb = reinterpret_cast<float*>(smem);                               // [4 waves][128]
+#pragma unroll
+  for (int qq = 0; qq < (SC ? 4 : 2); ++qq)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = row16_sum(st[qq][j]);
+      if (r == 0) sb[wv * 128 + qq * 32 + 8 * gq + j] = v;
+    }
+  __syncthreads();
+  if (t < (SC ? 128 : 64)) {
+    const float v = (sb[t] + sb[128 + t]) + (sb[256 + t] + sb[384 + t]);
+    float* dst = t < 64 ? a.stats : a.stats_sc;
+    if (dst) dst[(long)blockIdx.x * 64 + (t & 63)] = v;
+  }
+}
+
+bool conv3_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win) {
+  static const bool env = [] { const char* e = getenv("MMVAE_CONV3_STREAM"); return !(e && e[0] == '0'); }();
+  return env && dt == DT_BF16 && Cin == 32 && Cout == 32 && k == 3 && p == 1 && (s == 1 || s == 2) && Hin == Win && Win == 16 * s;
+}
+
+// y [N][Ho][16][32] = conv3x3(x [N][s*Ho][s*16][32], stride s, pad 1) with the packed [32][9][32] weights; wsc / ysc / stats_sc (optional, s = 2):
+// the 1x1 stride-2 shortcut on the same input, packed [32][32].  Returns the number of partial rows (> 0) or an error.
+int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const void* wsc, void* y, void* ysc, const float* pro_scale,
+                        const float* pro_shift, int pro_relu, float* stats, float* stats_sc, int N, int Ho, hipStream_t s) {
+  if (dt != DT_BF16 || (stride != 1 && stride != 2) || (wsc && stride != 2) || ((wsc != nullptr) != (ysc != nullptr))) {
+    set_error("conv3_stream: bf16, stride 1 or 2, shortcut only with stride 2"); return MMVAE_ERR_UNSUPPORTED;
+  }
+  Conv3StreamArgs a; memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.wsc = wsc; a.y = y; a.ysc = ysc; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu;
+  a.stats = stats; a.stats_sc = stats_sc; a.N = N; a.Ho = Ho; a.Hi = stride * Ho;
+  a.HS = Ho % 8 == 0 ? 8 : Ho;
+  a.nunits = N * (Ho / a.HS);
+  int gx = 512;
+  while (gx > 8 && (long)gx * 4 > a.nunits) gx -= 8;
+  const bool pro = pro_scale != nullptr;
+  const size_t lds = 2048 + 4 * (size_t)((3 + stride) * (stride * 16 + 2) * 64);
+#define MMVAE_C3(S_, SC_, P_) hipLaunchKernelGGL((conv3_stream_kernel<S_, SC_, P_>), dim3(gx), dim3(256), lds, s, a)
+  if (stride == 2) { if (wsc) { if (pro) MMVAE_C3(2, true, true); else MMVAE_C3(2, true, false); } else { if (pro) MMVAE_C3(2, false, true); else MMVAE_C3(2, false, false); } }
+  else { if (pro) MMVAE_C3(1, false, true); else MMVAE_C3(1, false, false); }
+#undef MMVAE_C3
+  const int rc = check_launch("conv3_stream");
+  return rc ? rc : gx;
+}
+
+}  // namespace mmvae

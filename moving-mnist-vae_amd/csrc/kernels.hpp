@@ -194,6 +194,11 @@ int launch_tail_wgrad(int dt, const void* x, const float* dy, float* dW, float* 
 
 // stem backward in one pass (stem_bwd.hip): BatchNorm sums + the three pixel reductions dW is an affine function of
 bool stem_bwd_fusable(int S);
+// 32 -> 32 channel 3x3 forward convs on 16-pixel-wide output maps as a per-wave stream, optionally with the block's 1x1 stride-2 shortcut
+// from the same input rows (conv_fstream.hip): returns stats rows (> 0) or an error
+bool conv3_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win);
+int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const void* wsc, void* y, void* ysc, const float* pro_scale,
+                        const float* pro_shift, int pro_relu, float* stats, float* stats_sc, int N, int Ho, hipStream_t s);
 // stem forward as a per-wave stream (bf16; stem_bwd.hip): returns stats rows (> 0) or an error
 bool stem_fwd_stream_ok(int dt, int S);
 int launch_stem_fwd_stream(int dt, const void* x, const float* w, void* y, float* stats, int N, int S, hipStream_t s);

@@ -504,20 +504,37 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
     const double cnt = (double)N * B.Hout * B.Wout;
     // shortcut branch (conv + its BatchNorm) on the side stream, concurrently with conv1 -> bn1 -> conv2 -> bn2
     static const bool side_fwd = [] { const char* e = getenv("MMVAE_SIDE_FWD"); return !(e && e[0] == '0'); }();
-    const bool fork = side_fwd && !B.identity;
+    // encoder.layer1 (32 -> 32 channels, bf16): conv1 AND the 1x1 shortcut from ONE read of the block input, conv2 likewise a per-wave
+    // stream (conv_fstream.hip); both BatchNorms finalise on the caller's stream
+    const bool stream1 = !B.identity && !B.c1.fp8 && !B.cs.fp8 && B.cs.k == 1 && B.cs.s == 2 &&
+                         conv3_stream_ok(dt(), B.Cin, B.C, B.c1.k, B.c1.s, B.c1.p, B.Hin, B.Win);
+    const bool stream2 = !B.c2.fp8 && conv3_stream_ok(dt(), B.C, B.C, B.c2.k, B.c2.s, B.c2.p, B.Hout, B.Wout);
+    const bool fork = side_fwd && !B.identity && !stream1;
     int np;
-    if (!B.identity) {
+    if (stream1) {
+      np = launch_conv3_stream(dt(), 2, xin, base + plan_.packed + B.c1.packD * (long)esz(), base + plan_.packed + B.cs.packD * (long)esz(), base + B.y1,
+                               base + B.ys, xs, xb, 1, stats, stats ? stats + kPartialFloats : nullptr, N, B.Hout, s);
+      MM_TRY(np);
+      MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, s, kPartialFloats, B.cs.wscale) : bn_eval(B.bs, params, bnbuf, base, s, B.cs.wscale));
+      MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s, 0, B.c1.wscale) : bn_eval(B.b1, params, bnbuf, base, s, B.c1.wscale));
+    } else if (!B.identity) {
       if (fork) MM_TRY(side_fork(s));
       hipStream_t ss = fork ? wgrad_stream(s) : s;
       np = run_down(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, dt(), ss);
       MM_TRY(np);
       MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats, B.cs.wscale) : bn_eval(B.bs, params, bnbuf, base, ss, B.cs.wscale));
     }
-    np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
-    MM_TRY(np);
-    MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s, 0, B.c1.wscale) : bn_eval(B.b1, params, bnbuf, base, s, B.c1.wscale));
-    np = run_down(B.c2, base, N, base + B.y1, B.Hout, B.Wout, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
-                  stats, 0, dt(), s);
+    if (!stream1) {
+      np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hout, B.Wout, xs, xb, 1, stats, 0, dt(), s);
+      MM_TRY(np);
+      MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, cnt, s, 0, B.c1.wscale) : bn_eval(B.b1, params, bnbuf, base, s, B.c1.wscale));
+    }
+    if (stream2)
+      np = launch_conv3_stream(dt(), 1, base + B.y1, base + plan_.packed + B.c2.packD * (long)esz(), nullptr, base + B.y2, nullptr, bnf(B.b1, base, 2),
+                               bnf(B.b1, base, 3), 1, stats, nullptr, N, B.Hout, s);
+    else
+      np = run_down(B.c2, base, N, base + B.y1, B.Hout, B.Wout, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
+                    stats, 0, dt(), s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s, 0, B.c2.wscale) : bn_eval(B.b2, params, bnbuf, base, s, B.c2.wscale));
     if (fork) MM_TRY(side_join(s));

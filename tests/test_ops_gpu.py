@@ -39,6 +39,7 @@ CONFIGS = [
     (16, 16, 3, 1, 1, 0, 64, 2), (32, 32, 4, 2, 1, 1, 16, 4), (16, 32, 3, 2, 1, 0, 64, 2),       # 256/512-pixel row tiles, LDS-staged epilogue
     (32, 16, 3, 1, 1, 0, 32, 3), (16, 16, 4, 2, 1, 0, 64, 2),
     (32, 16, 4, 2, 1, 1, 32, 5), (16, 16, 4, 2, 1, 1, 32, 70),                                   # streaming weight gradient (32x32 -> 64x64)
+    (32, 32, 3, 2, 1, 0, 32, 3), (32, 32, 3, 1, 1, 0, 16, 5), (32, 32, 3, 2, 1, 0, 32, 41),      # streaming 3x3 forward (encoder.layer1)
 ]
 
 
@@ -140,7 +141,7 @@ def test_conv_ops_match_torch(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4], CONFIGS[17], CONFIGS[22], CONFIGS[26], CONFIGS[12], CONFIGS[27], CONFIGS[-2], CONFIGS[-1]],
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4], CONFIGS[17], CONFIGS[22], CONFIGS[26], CONFIGS[12], CONFIGS[27], CONFIGS[-5], CONFIGS[-4], CONFIGS[-3], CONFIGS[-2]],
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv_ops_with_fused_bn_relu_prologue(cfg, dt):
     errs = run_config(cfg, dt, prologue=True)
