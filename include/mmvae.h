@@ -229,6 +229,11 @@ MMVAE_API int mmvae_convT_bwd_fused(int dtype, const void* x, const void* dy, co
  *   stats (nullable): per-image (sum, sumsq) of r_raw, [N][2]; returns N. */
 MMVAE_API int mmvae_tail_join_fwd(int dtype, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
                         const float* weight, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* stream);
+/* The same result as a per-wave MFMA stream (bf16, one output plane, 64x64 only; else MMVAE_ERR_UNSUPPORTED) -- what the network runs:
+ * the joined activation and the weights pass through bf16 on their way to the MFMA (mmvae_tail_join_fwd keeps both in f32).
+ * stats (nullable): partial (sum, sumsq) rows [rows][2] of r_raw; returns rows (<= N). */
+MMVAE_API int mmvae_tail_join_fwd_stream(int dtype, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
+                               const float* weight, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* stream);
 /* mmvae_tail_join_bwd_reduce: with g = conv_transpose2d(d_raw, weight, padding=1) masked by x > 0 (never stored), writes per-block
  *   partial sums partials[rows][3][16] = (sum g, sum g*y2, sum g*ys) and, when wpartials != NULL, the tail conv's weight-gradient
  *   partials wpartials[rows][16][9] (sum over pixels of x[ci] * d_raw[h+1-kh, w+1-kw]); returns rows (<= 1024).

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "mmvae_stem_fwd": (c_int, [c_int, P, P, P, c_int, c_int, P, P, P]),
     "mmvae_stem_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, P]),
     "mmvae_tail_join_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "mmvae_tail_join_fwd_stream": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_tail_join_bwd_reduce": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_tail_join_bwd_apply": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_convert": (c_int, [c_int, c_int, P, P, c_int64, P]),

@@ -339,6 +339,10 @@ int mmvae_tail_join_fwd(int dt, const void* y2, const float* s2, const float* b2
                         const float* w, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* st) {
   return launch_tail_join_fwd(dt, y2, s2, b2, ys, ss, bs, w, bias, r_raw, stats, N, H, W, S(st));
 }
+int mmvae_tail_join_fwd_stream(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
+                               const float* w, const float* bias, float* r_raw, float* stats, int N, int H, int W, void* st) {
+  return launch_tail_fwd_stream(dt, y2, s2, b2, ys, ss, bs, w, bias, r_raw, stats, N, H, W, S(st));
+}
 int mmvae_tail_join_bwd_reduce(int dt, const float* d_raw, const float* w, int oc, const void* y2, const float* s2, const float* b2,
                                const void* ys, const float* ss, const float* bs, float* partials, float* wpartials, int N, int H, int W,
                                void* st) {

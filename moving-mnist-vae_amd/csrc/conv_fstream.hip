@@ -200,4 +200,152 @@ int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const 
   return rc ? rc : gx;
 }
 
+// ---------------------------------------------------------------- last up-block join + tail conv (one output plane) as a stream
+// tail_fwd_stream_kernel: r_raw[n,0,h,w] = bias + sum_{kh,kw,c} x[n, h+kh-1, w+kw-1, c] * w[0][c][kh][kw] with the joined activation
+// x = relu(y2*s2+b2 + ys*ss+bs) recomputed on the way into a wave-private ring of rows (never stored).  tail_join_fwd_kernel (bn_elem.hip)
+// walks one image per block with per-tap dot products on the VALU and reads its 1.34 GB at 3.6 TB/s; here every wave streams strips of
+// rows, the next rows are in flight in registers, and the 16 x 9 reduction per pixel runs on the MFMA: two taps (2 x 16 channels) are one
+// K = 32 step, 6 steps per 16-pixel tile, the 15 unused output rows of the fragment cost nothing.  BatchNorm sums of the output
+// (one channel) are kept per wave over all its rows; one partial row per block.
+struct TailFwdStreamArgs {
+  const void* y2; const void* ys; const float* s2; const float* b2; const float* ss; const float* bs;
+  const float* w; const float* bias; float* r_raw; float* stats;
+  int N, H, HS, nunits;
+};
+
+__global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamArgs a) {
+  constexpr int KS = 3, W = 64, CB = 32;                                   // bytes per pixel (16 channels of bf16)
+  constexpr int WL = W + 2, ROWB = WL * CB, NSLOT = KS + 1, WAVE_LDS = NSLOT * ROWB, NPRIME = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
+  char* ring = smem + 64 + wv * WAVE_LDS;
+  for (int s = 0; s < NSLOT; ++s) {
+    if (lane < 2) *reinterpret_cast<Vec16*>(ring + s * ROWB + lane * 16) = Vec16{{0, 0, 0, 0}};
+    else if (lane < 4) *reinterpret_cast<Vec16*>(ring + s * ROWB + (WL - 1) * CB + (lane - 2) * 16) = Vec16{{0, 0, 0, 0}};
+  }
+  // A fragments: only output row 0 is real.  K-step (kh, 0): taps (kh,0),(kh,1); K-step (kh, 1): tap (kh,2) and a zero tap
+  Vec16 wA[KS][2];
+#pragma unroll
+  for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float f[8];
+      const int kw = 2 * half + (gq >> 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int c = 8 * (gq & 1) + j; f[j] = (r == 0 && kw < KS) ? a.w[c * 9 + kh * 3 + kw] : 0.f; }
+      wA[kh][half] = Elem<bf16_t>::pack(f);
+    }
+  const float bias = a.bias ? a.bias[0] : 0.f;
+  // join coefficients of the 8 channels this lane stages (vector lane + 64k of a row: channels 8 * (lane & 1) ..)
+  float c2s[8], c2b[8], css[8];
+  {
+    const int c = (lane & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c2s[j] = a.s2[c + j]; c2b[j] = a.b2[c + j] + a.bs[c + j]; css[j] = a.ss[c + j]; }
+  }
+  float st1 = 0.f, st2 = 0.f;
+  const int nblk = gridDim.x;
+  int u_first, u_step, u_end;
+  if ((nblk & 7) == 0) {
+    const int per = (a.nunits + 7) >> 3;
+    const int lo_u = (blockIdx.x & 7) * per;
+    u_first = lo_u + (blockIdx.x >> 3) * 4 + wv; u_step = (nblk >> 3) * 4; u_end = min(a.nunits, lo_u + per);
+  } else { u_first = blockIdx.x * 4 + wv; u_step = nblk * 4; u_end = a.nunits; }
+  const int nstrips = a.H / a.HS;
+  const int nq = a.HS + NPRIME;
+  Vec16 v2[2], vs[2];
+  auto issue = [&](int u, int q) {
+    const int n = u / nstrips, oh0 = (u - n * nstrips) * a.HS;
+    const int row = oh0 + q - NPRIME + 1;                                   // the row arriving at step q
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      v2[k] = Vec16{{0, 0, 0, 0}}; vs[k] = Vec16{{0, 0, 0, 0}};
+      if (row >= 0 && row < a.H) {
+        const long off = (((long)n * a.H + row) * W) * CB + (lane + 64 * k) * 16;
+        v2[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.y2) + off);
+        vs[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.ys) + off);
+      }
+    }
+  };
+  auto commit = [&](int u, int q) {
+    const int n = u / nstrips, oh0 = (u - n * nstrips) * a.HS;
+    const int row = oh0 + q - NPRIME + 1;
+    const bool in = row >= 0 && row < a.H;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float f2[8], fs[8];
+      Elem<bf16_t>::unpack(v2[k], f2);
+      Elem<bf16_t>::unpack(vs[k], fs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f2[j] = in ? fmaxf(f2[j] * c2s[j] + c2b[j] + fs[j] * css[j], 0.f) : 0.f;
+      *reinterpret_cast<Vec16*>(ring + ((row + 4 * NSLOT) % NSLOT) * ROWB + CB + (lane + 64 * k) * 16) = Elem<bf16_t>::pack(f2);
+    }
+    (void)n;
+  };
+  int u = u_first, q = 0;
+  if (u < u_end) issue(u, 0);
+  while (u < u_end) {
+    commit(u, q);
+    int un = u, qn = q + 1;
+    if (qn == nq) { un = u + u_step; qn = 0; }
+    if (un < u_end) issue(un, qn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q >= NPRIME) {
+      const int n = u / nstrips, oh = (u - n * nstrips) * a.HS + q - NPRIME;
+      f32x4 acc[4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) acc[pt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+        const char* rowp = ring + ((oh - 1 + kh + 4 * NSLOT) % NSLOT) * ROWB;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) {
+            // k = 8gq ..: tap kw = 2*half + (gq >> 1) (kw = 3: the A fragment is zero there; the read stays inside the row), channels 8*(gq & 1) ..
+            const int kw = 2 * half + (gq >> 1);
+            const Vec16 b = *reinterpret_cast<const Vec16*>(rowp + (16 * pt + r + (kw < KS ? kw : 0)) * CB + (gq & 1) * 16);
+            acc[pt] = mma_bf16(wA[kh][half], b, acc[pt]);
+          }
+      }
+      if (gq == 0) {                                                        // D row 0 lives in lanes gq = 0, element 0: pixel 16pt + r
+        float* orow = a.r_raw + ((long)n * a.H + oh) * W + r;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+          const float v = acc[pt][0] + bias;
+          orow[16 * pt] = v;
+          st1 += v; st2 += v * v;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u = un; q = qn;
+  }
+  // sums: lanes gq = 0 of a wave (16 lanes = one DPP row), then the four waves in order
+  st1 = row16_sum(st1); st2 = row16_sum(st2);
+  float* sb = reinterpret_cast<float*>(smem);
+  if (lane == 0) { sb[wv * 2] = st1; sb[wv * 2 + 1] = st2; }
+  __syncthreads();
+  if (a.stats && t < 2) a.stats[(long)blockIdx.x * 2 + t] = (sb[t] + sb[2 + t]) + (sb[4 + t] + sb[6 + t]);
+}
+
+bool tail_fwd_stream_ok(int dt, int OC, int H, int W) {
+  static const bool env = [] { const char* e = getenv("MMVAE_TAIL_FWD_STREAM"); return !(e && e[0] == '0'); }();
+  return env && dt == DT_BF16 && OC == 1 && W == 64 && H == 64;
+}
+// returns the number of partial rows [rows][2][1] (> 0) or an error
+int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs, const float* w,
+                           const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s) {
+  if (!tail_fwd_stream_ok(dt, 1, H, W)) { set_error("tail_fwd_stream: bf16, one output plane, 64x64"); return MMVAE_ERR_UNSUPPORTED; }
+  TailFwdStreamArgs a; memset(&a, 0, sizeof(a));
+  a.y2 = y2; a.ys = ys; a.s2 = s2; a.b2 = b2; a.ss = ss; a.bs = bs; a.w = w; a.bias = bias; a.r_raw = r_raw; a.stats = stats;
+  a.N = N; a.H = H; a.HS = 16; a.nunits = N * (H / a.HS);
+  int gx = 512;                                              // rows of `stats` <= N: the entry point's contract is an [N][2] buffer
+  while (gx > 1 && (long)gx * 4 > a.nunits) gx -= gx > 8 ? 8 : 1;
+  const size_t lds = 64 + 4 * (size_t)(4 * 66 * 32);
+  hipLaunchKernelGGL(tail_fwd_stream_kernel, dim3(gx), dim3(256), lds, s, a);
+  const int rc = check_launch("tail_fwd_stream");
+  return rc ? rc : gx;
+}
+
 }  // namespace mmvae

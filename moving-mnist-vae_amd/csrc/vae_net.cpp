@@ -770,8 +770,12 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   static const bool tail_direct_f = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
   if (tail_fwd_fused()) {
     const Block& B = dec.back();
-    np = launch_tail_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
-                              params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
+    if (tail_fwd_stream_ok(dt(), cfg.out_ch, Sd, Sd))
+      np = launch_tail_fwd_stream(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
+                                  params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
+    else
+      np = launch_tail_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
+                                params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
     MM_TRY(np);
     if (training) MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
   } else if (tail_direct_f) {

@@ -95,6 +95,34 @@ def test_tail_join_fwd(shape, dt):
     assert torch.allclose(sh[:, 1], (ref ** 2).sum((1, 2, 3)), rtol=2e-4)
 
 
+@pytest.mark.parametrize("N", [1, 3, 40])
+def test_tail_join_fwd_stream(N):
+    """The MFMA stream form the network runs (bf16, 64x64, one plane): joined activation and weights are rounded to bf16 on their way
+    to the MFMA, hence 1e-2 of the largest output; the partial (sum, sumsq) rows add up to the sums of the result it wrote."""
+    L = _lib()
+    lib = L.lib()
+    shape = (N, 64, 64, 1)
+    y2, ys, s2, b2, ss, bs, w, bias, _ = _case(shape, "bf16")
+    st = torch.cuda.current_stream().cuda_stream
+    y2d, ysd = _nhwc(y2, "bf16"), _nhwc(ys, "bf16")
+    dev = [t.cuda() for t in (s2, b2, ss, bs, w, bias)]
+    r = torch.full((N, 1, 64, 64), float("nan"), device="cuda")
+    stats = torch.zeros(max(N, 1), 2, device="cuda")
+    rows = L.check(lib.mmvae_tail_join_fwd_stream(1, L.ptr(y2d), L.ptr(dev[0]), L.ptr(dev[1]), L.ptr(ysd), L.ptr(dev[2]), L.ptr(dev[3]), L.ptr(dev[4]),
+                                                  L.ptr(dev[5]), L.ptr(r), L.ptr(stats), N, 64, 64, st), "tail_join_fwd_stream")
+    torch.cuda.synchronize()
+    assert 1 <= rows <= N
+    ref = F.conv2d(_join(y2, s2, b2, ys, ss, bs), _round(w, "bf16"), bias, padding=1)
+    err = ((r.cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 1e-2, err
+    sh = stats[:rows].sum(0).cpu()
+    got = r.cpu()
+    assert abs(sh[0].item() - got.sum().item()) <= 1e-4 * got.abs().sum().item()
+    assert abs(sh[1].item() - (got ** 2).sum().item()) <= 1e-4 * (got ** 2).sum().item()
+    assert lib.mmvae_tail_join_fwd_stream(1, L.ptr(y2d), L.ptr(dev[0]), L.ptr(dev[1]), L.ptr(ysd), L.ptr(dev[2]), L.ptr(dev[3]), L.ptr(dev[4]), L.ptr(dev[5]),
+                                          L.ptr(r), L.ptr(stats), N, 32, 32, st) < 0
+
+
 @pytest.mark.parametrize("wgrad", [False, True])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
