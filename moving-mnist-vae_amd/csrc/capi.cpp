@@ -220,6 +220,10 @@ int mmvae_conv2d_fwd(int dt, int transposed, const void* x, const float* w, void
     if (w) { int rc = op_pack_down(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc; }
     return op_run_down(dt, dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st), q);
   }
+  if (convT4_stream_ok(dt, Cin, Cout, k, s, p, H, W)) {                   // the decoder's widest ConvT layers: per-wave stream
+    if (w) { int rc = op_pack_up(dt, g, w, scratch, S(st)); if (rc < 0) return rc; }
+    return launch_convT4_stream(dt, x, scratch, y, ps, pb, relu, stats, N, H, S(st));
+  }
   q.wfrag = op_frag_up(dt, g, Ho, Wo);
   if (w) { int rc = op_pack_up(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc; }
   return op_run_up(dt, g, scratch, N, x, H, W, y, Ho, Wo, ps, pb, relu, stats, 0, S(st), q);

@@ -329,6 +329,162 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamAr
   if (a.stats && t < 2) a.stats[(long)blockIdx.x * 2 + t] = (sb[t] + sb[2 + t]) + (sb[4 + t] + sb[6 + t]);
 }
 
+// ---------------------------------------------------------------- ConvTranspose2d(16 -> 16, k4 s2 p1) forward as a stream
+// convT4_stream_kernel: the decoder's widest layers (uplayer5.conv2 / .upsample: 32x32 -> 64x64, 839 MB each at N = 5120; uplayer4.conv2:
+// 16x16 -> 32x32).  The patch-tile kernel moves them at 1.5-3.5 TB/s.  Here a wave keeps a ring of INPUT rows (fused BN+ReLU on the way
+// in) and produces the two output rows 2q, 2q+1 of input row q: per output row and column parity the 2 x 2 contributing taps x 16
+// channels are two K = 32 MFMA steps per 16-pixel tile (A = the packed per-phase weights, 8 fragments resident; B = 16-byte reads of
+// ring pixels), the results of both parities are interleaved into a wave-private LDS row and leave as whole 16-byte-per-lane stores;
+// BatchNorm sums from the f32 results.
+struct ConvT4StreamArgs {
+  const void* x; const void* w; void* y;
+  const float* pro_scale; const float* pro_shift; int pro_relu;
+  float* stats;                           // partial rows [blocks][2][16] (nullable)
+  int N, Hi, HS, nunits;
+};
+
+template <int WIN, bool PRO>
+__global__ __launch_bounds__(256, 3) void convT4_stream_kernel(ConvT4StreamArgs a) {
+  constexpr int CB = 32, WL = WIN + 2, ROWB = WL * CB, NSLOT = 4, NPRIME = 2;
+  constexpr int OROWB = 2 * WIN * CB;                                       // one output row
+  constexpr int WAVE_LDS = NSLOT * ROWB + OROWB;
+  constexpr int XV = (WIN * CB + 1023) / 1024;                              // input-row vectors per lane (WIN = 32: 1; 16: 1, half the lanes)
+  constexpr int NPT = WIN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
+  char* ring = smem + 1024 + wv * WAVE_LDS;
+  char* orow = ring + NSLOT * ROWB;
+  for (int s = 0; s < NSLOT; ++s) {
+    if (lane < 2) *reinterpret_cast<Vec16*>(ring + s * ROWB + lane * 16) = Vec16{{0, 0, 0, 0}};
+    else if (lane < 4) *reinterpret_cast<Vec16*>(ring + s * ROWB + (WL - 1) * CB + (lane - 2) * 16) = Vec16{{0, 0, 0, 0}};
+  }
+  // A[phase = 2*ph + pw][th]: row r = output channel, k = 8gq ..: tap (th, tw = gq >> 1) of the phase, input channels 8*(gq & 1) ..
+  Vec16 wA[4][2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+      wA[p][th] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.w) + p * 2048 + r * 128 + th * 64 + gq * 16);
+  // input offsets of the taps (op_pack_up's order): rows ph = 0: dh = {0, -1}, ph = 1: {+1, 0}; columns likewise
+  const int dwl[2] = {(gq >> 1) ? -1 : 0, (gq >> 1) ? 0 : 1};               // this lane's column offset for pw = 0 / 1
+  float psc[8], psh[8];
+  if (PRO) {
+    const int c = (lane & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { psc[j] = a.pro_scale[c + j]; psh[j] = a.pro_shift[c + j]; }
+  }
+  const float lo = a.pro_relu ? 0.f : -__builtin_inff();
+  float st1[4] = {0, 0, 0, 0}, st2[4] = {0, 0, 0, 0};
+  const int nblk = gridDim.x;
+  int u_first, u_step, u_end;
+  if ((nblk & 7) == 0) {
+    const int per = (a.nunits + 7) >> 3;
+    const int lo_u = (blockIdx.x & 7) * per;
+    u_first = lo_u + (blockIdx.x >> 3) * 4 + wv; u_step = (nblk >> 3) * 4; u_end = min(a.nunits, lo_u + per);
+  } else { u_first = blockIdx.x * 4 + wv; u_step = nblk * 4; u_end = a.nunits; }
+  const int nstrips = a.Hi / a.HS;
+  const int nq = a.HS + NPRIME;
+  const bool xlane = lane * 16 < WIN * CB;                                  // WIN = 16: a row is 512 bytes, lanes 0-31 stage it
+  Vec16 xv = Vec16{{0, 0, 0, 0}};
+  auto issue = [&](int u, int q) {
+    const int n = u / nstrips, q0 = (u - n * nstrips) * a.HS;
+    const int row = q0 + q - NPRIME + 1;
+    xv = Vec16{{0, 0, 0, 0}};
+    if (xlane && row >= 0 && row < a.Hi) xv = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.x) + (((long)n * a.Hi + row) * WIN) * CB + lane * 16);
+  };
+  auto commit = [&](int u, int q) {
+    const int n = u / nstrips, q0 = (u - n * nstrips) * a.HS;
+    const int row = q0 + q - NPRIME + 1;
+    if (xlane) {
+      Vec16 v = xv;
+      if (PRO && row >= 0 && row < a.Hi) {
+        float f[8];
+        Elem<bf16_t>::unpack(v, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * psc[j] + psh[j], lo);
+        v = Elem<bf16_t>::pack(f);
+      }
+      *reinterpret_cast<Vec16*>(ring + ((row + 4 * NSLOT) % NSLOT) * ROWB + CB + lane * 16) = v;
+    }
+    (void)n; (void)XV;
+  };
+  int u = u_first, q = 0;
+  if (u < u_end) issue(u, 0);
+  while (u < u_end) {
+    commit(u, q);
+    int un = u, qn = q + 1;
+    if (qn == nq) { un = u + u_step; qn = 0; }
+    if (un < u_end) issue(un, qn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q >= NPRIME) {
+      const int n = u / nstrips, iq = (u - n * nstrips) * a.HS + q - NPRIME;          // input row
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+          f32x4 acc[NPT];
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) acc[pt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+          for (int th = 0; th < 2; ++th) {
+            const int dh = ph == 0 ? (th == 0 ? 0 : -1) : (th == 0 ? 1 : 0);
+            const char* rowp = ring + ((iq + dh + 4 * NSLOT) % NSLOT) * ROWB;
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+              const Vec16 b = *reinterpret_cast<const Vec16*>(rowp + (16 * pt + r + dwl[pw] + 1) * CB + (gq & 1) * 16);
+              acc[pt] = mma_bf16(wA[2 * ph + pw][th], b, acc[pt]);
+            }
+          }
+          // lane (r = input column p, gq) holds output channels 4gq .. 4gq+3 of output pixel 2p + pw
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { st1[j] += acc[pt][j]; st2[j] += acc[pt][j] * acc[pt][j]; }
+            uint2 o;
+            o.x = pack2_bf16(acc[pt][0], acc[pt][1]); o.y = pack2_bf16(acc[pt][2], acc[pt][3]);
+            *reinterpret_cast<uint2*>(orow + (2 * (16 * pt + r) + pw) * CB + gq * 8) = o;
+          }
+        }
+        // the finished output row 2*iq + ph leaves as 16 bytes per lane
+        char* dst = reinterpret_cast<char*>(a.y) + (((long)n * (2 * a.Hi) + 2 * iq + ph) * (2 * WIN)) * CB;
+#pragma unroll
+        for (int k = 0; k < OROWB / 1024; ++k) *reinterpret_cast<Vec16*>(dst + (lane + 64 * k) * 16) = *reinterpret_cast<const Vec16*>(orow + (lane + 64 * k) * 16);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u = un; q = qn;
+  }
+  float* sb = reinterpret_cast<float*>(smem);                               // [4 waves][32]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v1 = row16_sum(st1[j]), v2 = row16_sum(st2[j]);
+    if (r == 0) { sb[wv * 32 + 4 * gq + j] = v1; sb[wv * 32 + 16 + 4 * gq + j] = v2; }
+  }
+  __syncthreads();
+  if (a.stats && t < 32) a.stats[(long)blockIdx.x * 32 + t] = (sb[t] + sb[32 + t]) + (sb[64 + t] + sb[96 + t]);
+}
+
+bool convT4_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win) {
+  static const bool env = [] { const char* e = getenv("MMVAE_CONVT4_STREAM"); return !(e && e[0] == '0'); }();
+  return env && dt == DT_BF16 && Cin == 16 && Cout == 16 && k == 4 && s == 2 && p == 1 && Hin == Win && (Win == 32 || Win == 16);
+}
+// y [N][2H][2H][16] = conv_transpose2d(x [N][H][H][16]) with the packed per-phase "up" weights; returns stats rows (> 0) or an error
+int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const float* pro_scale, const float* pro_shift, int pro_relu, float* stats,
+                         int N, int Hin, hipStream_t s) {
+  if (!convT4_stream_ok(dt, 16, 16, 4, 2, 1, Hin, Hin)) { set_error("convT4_stream: bf16, 16 -> 16 channels, k4 s2 p1, 16x16 or 32x32 input"); return MMVAE_ERR_UNSUPPORTED; }
+  ConvT4StreamArgs a; memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w_up; a.y = y; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu; a.stats = stats;
+  a.N = N; a.Hi = Hin; a.HS = Hin % 8 == 0 ? 8 : Hin; a.nunits = N * (Hin / a.HS);
+  int gx = 768;
+  while (gx > 8 && (long)gx * 4 > a.nunits) gx -= 8;
+  const bool pro = pro_scale != nullptr;
+  const size_t lds = 1024 + 4 * (size_t)(4 * (Hin + 2) * 32 + 2 * Hin * 32);
+  if (Hin == 32) { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<32, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<32, false>), dim3(gx), dim3(256), lds, s, a); }
+  else { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<16, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<16, false>), dim3(gx), dim3(256), lds, s, a); }
+  const int rc = check_launch("convT4_stream");
+  return rc ? rc : gx;
+}
+
 bool tail_fwd_stream_ok(int dt, int OC, int H, int W) {
   static const bool env = [] { const char* e = getenv("MMVAE_TAIL_FWD_STREAM"); return !(e && e[0] == '0'); }();
   return env && dt == DT_BF16 && OC == 1 && W == 64 && H == 64;

@@ -199,6 +199,10 @@ bool stem_bwd_fusable(int S);
 bool conv3_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win);
 int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const void* wsc, void* y, void* ysc, const float* pro_scale,
                         const float* pro_shift, int pro_relu, float* stats, float* stats_sc, int N, int Ho, hipStream_t s);
+// ConvTranspose2d(16 -> 16, k4 s2 p1) forward on 16x16 / 32x32 inputs as a per-wave stream (conv_fstream.hip)
+bool convT4_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win);
+int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const float* pro_scale, const float* pro_shift, int pro_relu, float* stats,
+                         int N, int Hin, hipStream_t s);
 // last up-block join + one-plane tail conv as a per-wave MFMA stream (conv_fstream.hip; bf16, 64x64): returns stats rows or an error
 bool tail_fwd_stream_ok(int dt, int OC, int H, int W);
 int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs, const float* w,

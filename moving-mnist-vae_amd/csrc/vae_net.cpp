@@ -745,7 +745,11 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     if (!B.identity) {
       if (fork) MM_TRY(side_fork(s));
       hipStream_t ss = fork ? wgrad_stream(s) : s;
-      np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, ss);
+      if (!B.cs.fp8 && convT4_stream_ok(dt(), B.cs.D0, B.cs.D1, B.cs.k, B.cs.s, B.cs.p, B.Hin, B.Win))
+        np = launch_convT4_stream(dt(), xin, base + plan_.packed + B.cs.packU * (long)esz(), base + B.ys, xs, xb, 1, stats ? stats + kPartialFloats : nullptr,
+                                  N, B.Hin, ss);
+      else
+        np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, ss);
       MM_TRY(np);
       MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats, B.cs.wscale) : bn_eval(B.bs, params, bnbuf, base, ss, B.cs.wscale));
     }
@@ -755,7 +759,11 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     if (B.identity)    // 3x3 Conv2d, shape preserving
       np = run_down(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, dt(), s);
     else
-      np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
+      if (!B.c2.fp8 && convT4_stream_ok(dt(), B.c2.D0, B.c2.D1, B.c2.k, B.c2.s, B.c2.p, B.Hin, B.Win))   // per-wave stream (conv_fstream.hip)
+        np = launch_convT4_stream(dt(), base + B.y1, base + plan_.packed + B.c2.packU * (long)esz(), base + B.y2, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
+                                  stats, N, B.Hin, s);
+      else
+        np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s, 0, B.c2.wscale) : bn_eval(B.b2, params, bnbuf, base, s, B.c2.wscale));
     if (fork) MM_TRY(side_join(s));
