@@ -146,8 +146,8 @@ def pmc_traffic(kernel_key, N):
 
 
 def dominant_kernel_roofline(M, device, N, reps=20):
-    """HBM roofline of the dominant kernel class, measured live with events on the launch stream: the gather-form
-    implicit-GEMM at the decoder's widest layer (decoder.uplayer5.0.conv2, ConvTranspose2d 16->16 k4 s2, 32^2 -> 64^2).
+    """HBM roofline of the dominant kernel class, measured live with events on the launch stream: the streaming
+    ConvTranspose2d forward at the decoder's widest layer (decoder.uplayer5.0.conv2, ConvTranspose2d 16->16 k4 s2, 32^2 -> 64^2).
     Algorithmic bytes per launch = input + output activations (bf16) + weights, each touched once."""
     L = importlib.import_module(PKG + "._lib")
     lib = L.lib()
@@ -179,7 +179,7 @@ def dominant_kernel_roofline(M, device, N, reps=20):
     traffic, src = pmc_traffic("uplayer5.conv2.fwd", N)
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": src,
-            "kernel": "patch_conv_kernel<bf16,bf16,1,4,false,4,true> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16->16 k4 s2, 32x32 -> 64x64; all 4 stride-phases from one LDS patch; isolated launches, cold input)",
+            "kernel": "convT4_stream_kernel<32> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16->16 k4 s2, 32x32 -> 64x64; per-wave stream: input-row ring in LDS, 2x2 taps x 16 channels per MFMA K-step, 16-byte stores; isolated launches, cold input)",
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
 
 

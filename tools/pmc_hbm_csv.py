@@ -3,7 +3,8 @@ MI355X guide prescribes) of `bench.py --steps 1 --warmup 1` -> rows of profiles/
 bench.py only quotes them for the build they were measured on.
   fetch_bytes = 2 * FETCH_SIZE * 1024   (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes; unit KB)
   write_bytes = WRITE_SIZE * 1024
-keys: uplayer5.conv2.fwd   the last patch_conv_kernel dispatch before the tail forward kernel (decoder.uplayer5.0.conv2 forward)
+keys: uplayer5.conv2.fwd   the last convT4_stream_kernel (else patch_conv_kernel) dispatch before the tail forward kernel
+      (decoder.uplayer5.0.conv2 forward)
       uplayer5.join_bwd_apply   the second tail_join_bwd_kernel dispatch of the step (apply pass)
       __step__   every dispatch of the last train step (between two Adam kernels)
 usage: python tools/pmc_hbm_csv.py <fetch counter_collection.csv> <write counter_collection.csv> <frames> > profiles/rNN_pmc_hbm.csv"""
@@ -36,7 +37,8 @@ def pick(step):
     names = [n for n, _ in step]
     out = {"__step__": sum(v for _, v in step)}
     j = next(i for i, n in enumerate(names) if "tail_join_fwd_kernel" in n or "tail_fwd_stream_kernel" in n)
-    i = max(k for k in range(j) if "patch_conv_kernel" in names[k])
+    conv = "convT4_stream_kernel" if any("convT4_stream_kernel" in n for n in names[:j]) else "patch_conv_kernel"
+    i = max(k for k in range(j) if conv in names[k])
     out["uplayer5.conv2.fwd"] = step[i][1]
     tb = [k for k, n in enumerate(names) if "tail_join_bwd_kernel" in n]
     out["uplayer5.join_bwd_apply"] = step[tb[1]][1]
