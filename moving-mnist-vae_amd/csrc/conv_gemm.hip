@@ -508,27 +508,31 @@ static bool deep2_enabled() {
   return enabled != 0 && !conv_force_v1();
 }
 // LDS bytes of a tile of npt*16 q-pixels (whole images)
-static size_t deep2_lds_for(int dt, int Cin, int Cout, int hw, int HiWi, int ntaps_all, int npt) {
+static size_t deep2_lds_for(int dt, int Cin, int Cout, int hw, int HiWi, int ntaps_all, int npt, int fp8 = 0) {
   DeepArgs b; memset(&b, 0, sizeof(b));
+  b.fp8 = fp8;
   b.Cin = Cin; b.Hi = HiWi; b.Wi = 1; b.ipt = npt * 16 / hw; b.npt = npt; b.ntaps_all = ntaps_all; b.nw = Cout / 32 < 8 ? Cout / 32 : 8;
   return deep2_conv_lds_bytes(b, dt);
 }
-bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, int ntaps_all) {
+bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, int ntaps_all, int fp8) {
   if (!deep2_enabled()) return false;
-  const int ES = dt == DT_F32 ? 4 : 2;
+  if (fp8 && dt != DT_BF16) return false;
+  const int ES = fp8 ? 1 : dt == DT_F32 ? 4 : 2;
   const int cpt = Cin * ES / 64;
-  const int c0 = ES == 2 ? 1 : 2;                   // 64-byte chunks of a tap at Cin = 32
-  if (Cin < 32 || (Cin * ES) % 64 != 0 || (cpt != c0 && cpt != 2 * c0 && cpt != 4 * c0 && cpt != 8 * c0)) return false;   // Cin 32, 64, 128, 256
+  const int c0 = ES == 4 ? 2 : 1;                   // 64-byte chunks of a tap at Cin = 32 (fp8: at Cin = 64)
+  if (Cin < (fp8 ? 64 : 32) || (Cin * ES) % 64 != 0 || (cpt != c0 && cpt != 2 * c0 && cpt != 4 * c0 && cpt != 8 * c0)) return false;   // Cin 32, 64, 128, 256
   if (Cout < 32 || Cout % 32 != 0 || (Cout > 256 && Cout % 256 != 0)) return false;
   if (Cin < 64 && Cout < 64) return false;          // the 16/32-channel layers are the patch-tile kernel's (weights resident in LDS)
   const int hw = Hq * Wq;
   if (hw < 1 || hw > 128 || Hq > 255 || Wq > 255 || ntaps_all < 1 || ntaps_all > kMaxTaps) return false;
   const int npt_min = hw > 64 ? 8 : hw > 32 ? 4 : 2;
-  return deep2_lds_for(dt, Cin, Cout, hw, Hi * Wi, ntaps_all, npt_min) <= 150 * 1024;
+  if (fp8 && cpt > 4) return false;
+  return deep2_lds_for(dt, Cin, Cout, hw, Hi * Wi, ntaps_all, npt_min, fp8) <= 150 * 1024;
 }
 static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   static const int npt_env = [] { const char* e = getenv("MMVAE_DEEP2_NPT"); return e ? atoi(e) : 0; }();
-  if (a.x_planar || a.y_planes || a.fp8 || a.x2) return 0;
+  if (a.x_planar || a.y_planes || a.x2) return 0;
+  if (a.fp8 && (!a.wfrag || a.accumulate || dt != DT_BF16 || out_dt != DT_BF16)) return 0;
   int Hq = 0, Wq = 0, ntaps_all = 0;
   for (int p = 0; p < a.nphase; ++p) {
     const Phase& ph = a.phases[p];
@@ -536,11 +540,12 @@ static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
     Hq = ph.Hq > Hq ? ph.Hq : Hq; Wq = ph.Wq > Wq ? ph.Wq : Wq;
     ntaps_all = ph.tap0 + ph.ntaps > ntaps_all ? ph.tap0 + ph.ntaps : ntaps_all;
   }
-  if (!deep2_shape_ok(dt, a.Cin, a.Cout, Hq, Wq, a.Hi, a.Wi, ntaps_all)) return 0;
+  if (!deep2_shape_ok(dt, a.Cin, a.Cout, Hq, Wq, a.Hi, a.Wi, ntaps_all, a.fp8)) return 0;
   if ((long)a.N * a.Ho * a.Wo * a.Cout >= (1L << 32)) return 0;
   const int ES = dt == DT_F32 ? 4 : 2, VE = 16 / ES;
-  const int cpt = a.Cin * ES / 64;
+  const int cpt = a.Cin * (a.fp8 ? 1 : ES) / 64;
   DeepArgs b; memset(&b, 0, sizeof(b));
+  b.fp8 = a.fp8;
   b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
   b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate; b.wfrag = a.wfrag;
   b.N = a.N; b.Hi = a.Hi; b.Wi = a.Wi; b.Cin = a.Cin; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = a.SI; b.SO = a.SO;
@@ -564,7 +569,7 @@ static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
     for (int npt = 8; npt >= 2 && !best; npt >>= 1) {
       if (npt_env && npt != npt_env && pass == 0) continue;
       if (hw > npt * 16) break;
-      const size_t lds = deep2_lds_for(dt, a.Cin, a.Cout, hw, a.Hi * a.Wi, ntaps_all, npt);
+      const size_t lds = deep2_lds_for(dt, a.Cin, a.Cout, hw, a.Hi * a.Wi, ntaps_all, npt, a.fp8);
       int ipt = npt * 16 / hw; if (ipt > a.N) ipt = a.N;
       const long ntiles = (a.N + ipt - 1) / ipt;
       if (pass == 0) {
@@ -621,6 +626,9 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
     // fp8 forward convolutions exist in the deep-layer kernel only (the packed weights are e4m3 bytes: no other kernel can read them)
     if (dt != DT_BF16 || out_dt != DT_BF16 || a.x2 || a.accumulate) { set_error("gather_gemm: fp8 needs the bf16 forward path"); return MMVAE_ERR_UNSUPPORTED; }
     a.cin_vecs = a.Cin / VE;
+    const int rc2 = try_deep2(dt, out_dt, a, s);
+    if (rc2 != 0) return rc2;
+    if (a.wfrag) { set_error("gather_gemm: fragment-major fp8 weights (Cin=%d Cout=%d) need the deep2 kernel", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }
     const int rc = try_deep(dt, out_dt, a, s);
     if (rc == 0) { set_error("gather_gemm: fp8 layer Cin=%d Cout=%d is not eligible for the deep-layer kernel", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }
     return rc;
@@ -999,6 +1007,13 @@ __device__ __forceinline__ long frag_index(int col, int kk, int Ktot) {
   const int blk = 2 * (col >> 5) + ((q >> 2) & 1), r = 4 * (q >> 3) + (q & 3);
   return (((long)blk * (Ktot / CK) + chunk) * 64 + (in / VE) * 16 + r) * VE + (in % VE);
 }
+// the same for e4m3 bytes: a 64-byte chunk is 64 k-values = two MFMA k-blocks; a lane's 16 bytes = its 8 bytes of block 0, then of block 1
+__device__ __forceinline__ long frag_index_f8(int col, int kk, int Ktot) {
+  const int chunk = kk >> 6, in = kk & 63, half = in >> 5, w = in & 31;
+  const int q = col & 31;
+  const int blk = 2 * (col >> 5) + ((q >> 2) & 1), r = 4 * (q >> 3) + (q & 3);
+  return (((long)blk * (Ktot >> 6) + chunk) * 64 + (w >> 3) * 16 + r) * 16 + half * 8 + (w & 7);
+}
 template <typename T>
 __global__ void pack_kernel(PackArgs a) {
   const long total = (long)a.cols * a.ntaps * a.K;
@@ -1034,7 +1049,7 @@ __global__ void pack_multi_kernel(PackMulti m) {
     const int col = (int)(q / a.ntaps);
     const bool real = (a.cols_valid <= 0 || col < a.cols_valid) && (a.K_valid <= 0 || k < a.K_valid);
     const float v = real ? a.src[(long)col * a.s_col + (long)k * a.s_k + a.tap_off[tp]] * a.scale : 0.f;
-    if (a.fp8) reinterpret_cast<unsigned char*>(a.dst)[i] = f32_to_e4m3(v);
+    if (a.fp8) reinterpret_cast<unsigned char*>(a.dst)[a.frag ? frag_index_f8(col, tp * a.K + k, a.ntaps * a.K) : i] = f32_to_e4m3(v);
     else Elem<T>::store(reinterpret_cast<T*>(a.dst) + (a.frag ? frag_index<T>(col, tp * a.K + k, a.ntaps * a.K) : i), v);
   }
 }
@@ -1066,7 +1081,6 @@ int launch_pack(int dt, const PackArgs& a, hipStream_t s) {
   if (total <= 0) return MMVAE_OK;
   if (g_pack_batching) {
     if (g_pack_n >= 256 || a.ntaps > 26) { set_error("pack batch overflow"); return MMVAE_ERR_ARG; }
-    if (a.frag && a.fp8) { set_error("pack: fragment-major fp8 is not a layout any kernel reads"); return MMVAE_ERR_UNSUPPORTED; }
     PackJob& j = g_pack_jobs[g_pack_n++];
     j.src = a.src; j.dst = a.dst; j.cols = a.cols; j.K = a.K; j.ntaps = a.ntaps; j.s_col = a.s_col; j.s_k = a.s_k;
     j.cols_valid = a.cols_valid; j.K_valid = a.K_valid; j.scale = a.scale; j.fp8 = (unsigned char)(a.fp8 ? 1 : 0); j.frag = (unsigned char)(a.frag ? 1 : 0);

@@ -17,9 +17,9 @@ inline int conv_down_size(int H, int k, int s, int p) { return (H + 2 * p - k) /
 // run_up launch of this geometry (large-side map Hl x Wl) goes to that kernel, i.e. whether to pack and run with the flag set.
 int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0, int frag = 0);
 int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0, int frag = 0);
-int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl);
+int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl, int fp8 = 0);
 // allow_empty_phases: the launch accumulates (or is a second source), so stride phases without a tap are skipped, not zero-filled
-int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases = 0);
+int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases = 0, int fp8 = 0);
 // x2 / w2 / Cin2 (optional): a second tensor on the q grid (= S for run_down, = the S-resolution grid for run_up) whose 1x1
 // convolution with the packed [Cout][Cin2] matrix w2 is added into the result (phase (0,0) of run_up) in the same kernel.
 struct SecondSrc {

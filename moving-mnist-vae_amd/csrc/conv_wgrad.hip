@@ -155,7 +155,7 @@ int launch_deep2_conv_bf16(const DeepArgs& a, int gx, hipStream_t s);
 int launch_deep2_conv_bf16_f32(const DeepArgs& a, int gx, hipStream_t s);
 
 size_t deep2_conv_lds_bytes(const DeepArgs& a, int dt) {
-  const size_t pitch = (size_t)a.Cin * dtype_size(dt) + 32;
+  const size_t pitch = a.fp8 ? (size_t)a.Cin + 16 : (size_t)a.Cin * dtype_size(dt) + 32;
   return (size_t)(a.ipt * a.Hi * a.Wi + 1) * pitch + (size_t)a.npt * 16 * 4 + (size_t)a.nw * 64 * 4 + (size_t)a.ntaps_all * a.npt * 16 * 2;
 }
 

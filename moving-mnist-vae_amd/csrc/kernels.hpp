@@ -41,7 +41,7 @@ struct GatherArgs {
 };
 // Shapes deep2_conv_kernel takes (conv_deep2.inc): the layers whose weights are packed fragment-major.  q grid Hq x Wq per phase
 // and image, input map Hi x Wi, ntaps over all phases.
-bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, int ntaps_all);
+bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, int ntaps_all, int fp8 = 0);   // fp8: e4m3 weights / LDS (bf16 storage)
 // out_dt: dtype of y (may be DT_F32 while x/w are bf16).  Returns the number of stats partial rows (>0) or an error (<0).
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s);
 constexpr int kGatherMaxGridX = 1024;

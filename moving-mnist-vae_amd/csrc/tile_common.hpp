@@ -39,6 +39,19 @@ template <> __device__ __forceinline__ void dstore4<bf16_t>(bf16_t* p, const flo
   *reinterpret_cast<uint2*>(p) = o;
 }
 
+// fp8 forward (BASELINE configs[4]): 8 f32 -> 8 OCP e4m3 bytes, saturating at the largest finite value (448)
+__device__ __forceinline__ uint2 pack8_fp8(const float* f) {
+  uint2 o; o.x = 0; o.y = 0;
+  float c[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = fminf(fmaxf(f[j], -448.f), 448.f);
+  o.x = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], o.x, false);
+  o.x = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], o.x, true);
+  o.y = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], o.y, false);
+  o.y = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], o.y, true);
+  return o;
+}
+
 // 8 consecutive output channels of one pixel
 template <typename TO> __device__ __forceinline__ void dstore8(TO* p, const float* v, bool acc);
 template <> __device__ __forceinline__ void dstore8<float>(float* p, const float* v, bool acc) {

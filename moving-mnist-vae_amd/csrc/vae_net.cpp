@@ -204,8 +204,9 @@ static inline ConvGeom geom(const ConvW& w) { return ConvGeom{w.D0, w.D1, w.k, w
 // of an fp8 layer carries its weight scale
 // The up form of a 1x1 stride-2 shortcut has stride phases without a tap: in this net it only ever accumulates into (or rides along
 // with) the main path's data gradient, so those phases are skipped.
-int Net::frag_down(const ConvW& w) const { return (w.Hl > 0 && !(w.fp8 && !w.tr)) ? op_frag_down(dt(), geom(w), w.Hl, w.Hl) : 0; }
-int Net::frag_up(const ConvW& w) const { return (w.Hl > 0 && !(w.fp8 && w.tr)) ? op_frag_up(dt(), geom(w), w.Hl, w.Hl, 1) : 0; }
+// (an fp8 layer's FORWARD pack is e4m3: fragment-major when the fp8 form of the kernel takes the shape)
+int Net::frag_down(const ConvW& w) const { return w.Hl > 0 ? op_frag_down(dt(), geom(w), w.Hl, w.Hl, (w.fp8 && !w.tr) ? 1 : 0) : 0; }
+int Net::frag_up(const ConvW& w) const { return w.Hl > 0 ? op_frag_up(dt(), geom(w), w.Hl, w.Hl, 1, (w.fp8 && w.tr) ? 1 : 0) : 0; }
 int Net::pack_down(const ConvW& w, const float* params, char* base, hipStream_t s) {
   return op_pack_down(dt(), geom(w), params + w.off, base + plan_.packed + w.packD * (long)esz(), s, w.wscale, (w.fp8 && !w.tr) ? 1 : 0,
                       frag_down(w));
