@@ -727,7 +727,10 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
   int wshift = 0;
   while ((1 << wshift) < W) ++wshift;
   const int ntiles = (int)((long)N * H * W / pt);
-  int blocks = ntiles < (APPLY ? kElemMaxBlocks : 1024) ? ntiles : (APPLY ? kElemMaxBlocks : 1024);
+  // apply: three 256-thread blocks fit a CU (launch bounds), so 768 blocks are exactly one resident round on 256 CUs; 2048 left the
+  // last 2/3 round to a third of the chip (535 -> 506 us at 5120 frames).  The reduce pass (two per CU) keeps its two full rounds.
+  const int cap = APPLY ? (OC == 1 ? 768 : kElemMaxBlocks) : 1024;
+  int blocks = ntiles < cap ? ntiles : cap;
   const TailG tg{d_raw, w, OC, H, W, wshift, ntiles};
   const int tile_floats = OC * (pt / W + 2) * (W + 2);
   const size_t sm = ((size_t)2 * tile_floats + (OC == 1 ? (wpartials ? 9 * cv * 4 : 0) : OC * 144) + (APPLY ? 64 : 256 * 3 * VE)) * sizeof(float);
