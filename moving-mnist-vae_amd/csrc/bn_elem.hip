@@ -717,9 +717,10 @@ __global__ __launch_bounds__(256, (OC1 && !WG) ? 3 : 2) void tail_join_bwd_kerne
 //   data gradient  g[ci][pixel] = sum_tap w[ci][tap] * d[pixel (+) tap]: ONE 16x16x32 MFMA per group -- A = the bf16 weights [ci][k],
 //     B[k][pixel] = the 9 shifted d_raw values of the pixel, as bf16 hi parts in k = 0..8 and lo parts (d - hi) in k = 16..24 against the
 //     same weights, so d_raw keeps (nearly) its f32 precision like in the VALU form;
-//   weight gradient dW[ci][tap] = sum_pixel x[pixel][ci] * d[pixel (+) tap]: one MFMA per wave and tile, K = the wave's 32 pixels -- x (bf16,
-//     what the forward's ring holds too) parked [pixel][16] in a wave-private LDS patch and read back channel-major (ds_read_b64_tr_b16),
-//     B = 8 consecutive d_raw values per lane (tap = r < 9).
+//   weight gradient dW[ci][tap] = sum_pixel x[pixel][ci] * d[pixel (+) tap] in FULL f32 (eight 16x16x4 f32 MFMAs per wave and tile, K = the
+//     wave's 32 pixels): this conv feeds a BatchNorm, so its true weight gradient is the small remainder of terms that cancel ~1000-fold
+//     and bf16 operands leave nothing of it (rel-L2 1.95 at config 2's size).  x goes through a wave-private f32 LDS patch
+//     [pixel][16] (bank-conflict-free in both directions), B = the lane's tap (r < 9) of d_raw at pixel 4m + gq.
 // Same tiles, d_raw staging, partial-row layouts and fixed summation order as the VALU form.
 __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, const float* __restrict__ ms, const float* __restrict__ mb,
                                                                   const float* __restrict__ ms1, const float* __restrict__ mb1,
@@ -731,8 +732,8 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
   const int R = PT >> tg.wshift, pitch = W + 2, rows = R + 2;
   const int tile_floats = (rows * pitch + 3) & ~3;
   float* sD = smem;                                                    // [2][rows][pitch]
-  char* sX = reinterpret_cast<char*>(smem + 2 * tile_floats);         // [4 waves][32 pixels][16 channels] bf16
-  float* sR = reinterpret_cast<float*>(sX + 4096);                    // [4][48] sums, [4][144] weight-gradient fragments
+  float* sX = smem + 2 * tile_floats;                                 // [4 waves][32 pixels][16 channels] f32
+  float* sR = sX + 4 * 512;                                           // [4][48] sums, [4][144] weight-gradient fragments
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
   const bool odd = gq & 1, lo_half = gq >= 2;
   for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;       // halo columns stay zero for the kernel's lifetime
@@ -751,12 +752,11 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
     acc[0][j] = 0.f; acc[1][j] = 0.f; acc[2][j] = 0.f;
   }
   f32x4 macc = {0.f, 0.f, 0.f, 0.f};
-  char* sXw = sX + wv * 1024;
+  float* sXw = sX + wv * 512;
   const int p0 = 32 * wv, pr = p0 >> tg.wshift, c0 = p0 & (W - 1);     // the wave's 32 pixels: one row (W >= 32)
-  // weight gradient operands: A = x^T out of the patch; B: lane (tap = r, k slice gq) reads d_raw of pixels c0 + 8gq .. + 7 shifted by its tap
-  const int a0 = (8 * gq + (r >> 2)) * 32 + (r & 3) * 8, a1 = a0 + 4 * 32;
+  // weight gradient operands of K step m: A[ci = r][k = gq] = x[pixel 4m + gq][r]; B[k = gq][tap = r] = d_raw of that pixel shifted by the tap
   const int tw = r < 9 ? r : 8, twh = tw / 3, tww = tw - 3 * twh;
-  const int wofs = (pr + 2 - twh) * pitch + c0 + 8 * gq + 2 - tww;
+  const int wofs = (pr + 2 - twh) * pitch + c0 + gq + 2 - tww;
   const int stage = rows * W;
   int buf = 0;
   uint2 q0[2], q1[2];
@@ -818,17 +818,13 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
         const float gg = x[j] > 0.f ? g[j] : 0.f;
         acc[0][j] += gg; acc[1][j] += gg * f0[j]; acc[2][j] += gg * f1[j];
       }
-      *reinterpret_cast<uint2*>(sXw + (16 * pt + r) * 32 + gq * 8) = make_uint2(pack2_bf16(x[0], x[1]), pack2_bf16(x[2], x[3]));
+      *reinterpret_cast<float4*>(sXw + (16 * pt + r) * 16 + 4 * gq) = make_float4(x[0], x[1], x[2], x[3]);
     }
-    {
-      Vec16 bf;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float d0 = sT[wofs + 2 * k], d1 = sT[wofs + 2 * k + 1];
-        bf.w[k] = r < 9 ? pack2_bf16(d0, d1) : 0u;
-      }
-      const Vec16 af = FragOps<bf16_t>::load(sXw, a0, a1);
-      macc = mma_bf16(af, bf, macc);
+    for (int m = 0; m < 8; ++m) {
+      const float av = sXw[(4 * m + gq) * 16 + r];
+      const float dv = sT[wofs + 4 * m];
+      macc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, r < 9 ? dv : 0.f, macc, 0, 0, 0);
     }
   }
   // ---- block sums: the 16 pixel lanes of a row (DPP), then the four waves in order through LDS
@@ -846,6 +842,105 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
   __syncthreads();
   if (tid < 48) partials[(long)blockIdx.x * 48 + tid] = (sR[tid] + sR[48 + tid]) + (sR[96 + tid] + sR[144 + tid]);
   if (tid < 144) wpartials[(long)blockIdx.x * 144 + tid] = (sR[192 + tid] + sR[336 + tid]) + (sR[480 + tid] + sR[624 + tid]);
+}
+
+// The apply pass in the same form: g from one hi/lo-split MFMA per 16 pixels, dy0 = A0 g + B0 y0 + C0 and dy1 = A1 g + B1 y1 + C1 for the
+// lane's four channels, 8-byte loads and stores.
+__global__ __launch_bounds__(256, 4) void tail_apply_mfma_kernel(TailG tg, const float* __restrict__ ms, const float* __restrict__ mb,
+                                                                 const float* __restrict__ ms1, const float* __restrict__ mb1,
+                                                                 const bf16_t* __restrict__ y0, const float* __restrict__ A0, const float* __restrict__ B0,
+                                                                 const float* __restrict__ C0, bf16_t* __restrict__ dy0, const bf16_t* __restrict__ y1,
+                                                                 const float* __restrict__ A1, const float* __restrict__ B1,
+                                                                 const float* __restrict__ C1, bf16_t* __restrict__ dy1) {
+  constexpr int PT = 128;
+  extern __shared__ float smem[];
+  const int W = tg.W, H = tg.H, hw = H * W;
+  const int R = PT >> tg.wshift, pitch = W + 2, rows = R + 2;
+  const int tile_floats = (rows * pitch + 3) & ~3;
+  float* sD = smem;                                                    // [2][rows][pitch]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
+  const bool odd = gq & 1, lo_half = gq >= 2;
+  for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;
+  Vec16 wA;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t0 = 8 * (gq & 1) + 2 * k;
+    wA.w[k] = pack2_bf16(t0 < 9 ? tg.w[r * 9 + t0] : 0.f, t0 + 1 < 9 ? tg.w[r * 9 + t0 + 1] : 0.f);
+  }
+  float msc[4], msh[4], msc1[4], msh1[4], ca0[4], cb0[4], cc0[4], ca1[4], cb1[4], cc1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = 4 * gq + j;
+    msc[j] = ms[ch]; msh[j] = mb[ch]; msc1[j] = ms1[ch]; msh1[j] = mb1[ch];
+    ca0[j] = A0[ch]; cb0[j] = B0[ch]; cc0[j] = C0[ch]; ca1[j] = A1[ch]; cb1[j] = B1[ch]; cc1[j] = C1[ch];
+  }
+  const int p0 = 32 * wv, pr = p0 >> tg.wshift, c0 = p0 & (W - 1);
+  const int stage = rows * W;
+  int buf = 0;
+  uint2 q0[2], q1[2];
+  float dpre[2] = {0.f, 0.f};
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const long e = ((long)t * PT + p0 + 16 * pt + r) * 16 + 4 * gq;
+      q0[pt] = load_nt(reinterpret_cast<const uint2*>(y0 + e));
+      q1[pt] = load_nt(reinterpret_cast<const uint2*>(y1 + e));
+    }
+    const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;      // uniform
+    const float* dp = tg.d_raw + (long)n * hw;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * 256, rr = e >> tg.wshift, c = e & (W - 1), h = h0 - 1 + rr;
+      dpre[k] = (e < stage && h >= 0 && h < H) ? dp[h * W + c] : 0.f;
+    }
+  };
+  __syncthreads();
+  if ((int)blockIdx.x < tg.ntiles) fetch(blockIdx.x);
+  for (int t = blockIdx.x; t < tg.ntiles; t += gridDim.x, buf ^= 1) {
+    float* sT = sD + buf * tile_floats;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * 256, rr = e >> tg.wshift, c = e & (W - 1);
+      if (e < stage) sT[rr * pitch + c + 1] = dpre[k];
+    }
+    uint2 c0v[2] = {q0[0], q0[1]}, c1v[2] = {q1[0], q1[1]};
+    if (t + (int)gridDim.x < tg.ntiles) fetch(t + gridDim.x);
+    __syncthreads();
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int base = (pr + 2) * pitch + c0 + 16 * pt + r + 2;
+      float dv[8];
+      dv[0] = sT[base - (odd ? 2 * pitch + 2 : 0)];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) {
+        const float v = sT[base - (k / 3) * pitch - (k % 3)];
+        dv[k] = odd ? 0.f : v;
+      }
+      Vec16 bf;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t hi = pack2_bf16(dv[2 * k], dv[2 * k + 1]);
+        const uint32_t lo = pack2_bf16(dv[2 * k] - __uint_as_float(hi << 16), dv[2 * k + 1] - __uint_as_float(hi & 0xffff0000u));
+        bf.w[k] = lo_half ? lo : hi;
+      }
+      const f32x4 g = mma_bf16(wA, bf, (f32x4){0.f, 0.f, 0.f, 0.f});
+      const float f0[4] = {__uint_as_float(c0v[pt].x << 16), __uint_as_float(c0v[pt].x & 0xffff0000u), __uint_as_float(c0v[pt].y << 16),
+                           __uint_as_float(c0v[pt].y & 0xffff0000u)};
+      const float f1[4] = {__uint_as_float(c1v[pt].x << 16), __uint_as_float(c1v[pt].x & 0xffff0000u), __uint_as_float(c1v[pt].y << 16),
+                           __uint_as_float(c1v[pt].y & 0xffff0000u)};
+      float r0[4], r1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x = (f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]);
+        const float gg = x > 0.f ? g[j] : 0.f;
+        r0[j] = ca0[j] * gg + cb0[j] * f0[j] + cc0[j];
+        r1[j] = ca1[j] * gg + cb1[j] * f1[j] + cc1[j];
+      }
+      const long e = ((long)t * PT + p0 + 16 * pt + r) * 16 + 4 * gq;
+      store_nt(reinterpret_cast<uint2*>(dy0 + e), make_uint2(pack2_bf16(r0[0], r0[1]), pack2_bf16(r0[2], r0[3])));
+      store_nt(reinterpret_cast<uint2*>(dy1 + e), make_uint2(pack2_bf16(r1[0], r1[1]), pack2_bf16(r1[2], r1[3])));
+    }
+  }
 }
 
 // Whether the tile walk above covers an (OC, H, W) output with element type dt; the caller keeps the separate dgrad otherwise.
@@ -876,12 +971,25 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
   const size_t sm = ((size_t)2 * tile_floats + (OC == 1 ? (wpartials ? 9 * cv * 4 : 0) : OC * 144) + (APPLY ? 64 : 256 * 3 * VE)) * sizeof(float);
 #define MMVAE_LAUNCH(T, OC1, WG) hipLaunchKernelGGL((tail_join_bwd_kernel<T, OC1, APPLY, WG>), dim3(blocks), dim3(256), sm, s, tg, ms, mb, ms1, mb1, \
     (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, partials, wpartials)
+  if constexpr (APPLY) {
+    static const bool mfma_apply_env = [] { const char* e = getenv("MMVAE_TAIL_APPLY_MFMA"); return !(e && e[0] == '0'); }();
+    if (dt != DT_F32 && OC == 1 && W >= 32 && mfma_apply_env) {
+      // measured at 5120 frames: 512 blocks 462 us, 640: 499, 704: 460, 768: 443, 896 / 1024: 521, 1280: 506 (five fit a CU) -- whole
+      // multiples of the CU count, and no more concurrent read + write streams than the memory system likes
+      const int nb = ntiles < 768 ? ntiles : 768;
+      const int tf = ((pt / W + 2) * (W + 2) + 3) & ~3;
+      hipLaunchKernelGGL(tail_apply_mfma_kernel, dim3(nb), dim3(256), (size_t)2 * tf * sizeof(float), s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, A0, B0, C0,
+                         (bf16_t*)dy0, (const bf16_t*)y1, A1, B1, C1, (bf16_t*)dy1);
+      const int rcm = check_launch("tail_apply_mfma");
+      return rcm ? rcm : nb;
+    }
+  }
   if constexpr (!APPLY) {
     static const bool mfma_env = [] { const char* e = getenv("MMVAE_TAIL_REDUCE_MFMA"); return !(e && e[0] == '0'); }();
     if (wpartials && dt != DT_F32 && OC == 1 && W >= 32 && mfma_env) {
-      const int nb = ntiles < 1024 ? ntiles : 1024;                  // four blocks per CU (114 VGPRs): one resident round
+      const int nb = ntiles < 1024 ? ntiles : 1024;                  // four blocks per CU (114 VGPRs): one resident round (314 us; 768: 345, 512: 411)
       const int tf = ((pt / W + 2) * (W + 2) + 3) & ~3;
-      const size_t lds = (size_t)2 * tf * sizeof(float) + 4096 + (192 + 576) * sizeof(float);
+      const size_t lds = ((size_t)2 * tf + 4 * 512 + 192 + 576) * sizeof(float);
       hipLaunchKernelGGL(tail_reduce_mfma_kernel, dim3(nb), dim3(256), lds, s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, (const bf16_t*)y1, partials, wpartials);
       const int rcm = check_launch("tail_reduce_mfma");
       return rcm ? rcm : nb;

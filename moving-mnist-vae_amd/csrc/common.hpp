@@ -29,6 +29,16 @@ __device__ __forceinline__ void store_nt(Vec16* p, const Vec16& q) {
   __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
 }
 
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+__device__ __forceinline__ uint2 load_nt(const uint2* p) {
+  const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void store_nt(uint2* p, const uint2& q) {
+  u32x2_t v; v.x = q.x; v.y = q.y;
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x2_t*>(p));
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
   return __uint_as_float(((uint32_t)b) << 16);
 }

@@ -162,9 +162,7 @@ def test_tail_join_bwd(shape, dt, wgrad):
     if wgrad:
         dw = wpart[:rows].sum(0).cpu().view(1, 16, 3, 3)
         err = ((dw - wr.grad).abs().max() / wr.grad.abs().max()).item()
-        # bf16: the weight gradient runs on the matrix cores with bf16 operands (the joined activation as the forward pass holds it,
-        # d_raw rounded once) like every other layer's; a sum of ~1e4 products of independently rounded factors is off by ~2^-9 of its scale
-        assert err < (1e-4 if dt == "f32" else 4e-3), (shape, dt, "wgrad", err)
+        assert err < (1e-4 if dt == "f32" else 2e-4), (shape, dt, "wgrad", err)
     # apply
     gen = torch.Generator().manual_seed(7)
     co = [torch.randn(16, generator=gen) for _ in range(6)]
