@@ -717,10 +717,12 @@ __global__ __launch_bounds__(256, (OC1 && !WG) ? 3 : 2) void tail_join_bwd_kerne
 //   data gradient  g[ci][pixel] = sum_tap w[ci][tap] * d[pixel (+) tap]: ONE 16x16x32 MFMA per group -- A = the bf16 weights [ci][k],
 //     B[k][pixel] = the 9 shifted d_raw values of the pixel, as bf16 hi parts in k = 0..8 and lo parts (d - hi) in k = 16..24 against the
 //     same weights, so d_raw keeps (nearly) its f32 precision like in the VALU form;
-//   weight gradient dW[ci][tap] = sum_pixel x[pixel][ci] * d[pixel (+) tap] in FULL f32 (eight 16x16x4 f32 MFMAs per wave and tile, K = the
-//     wave's 32 pixels): this conv feeds a BatchNorm, so its true weight gradient is the small remainder of terms that cancel ~1000-fold
-//     and bf16 operands leave nothing of it (rel-L2 1.95 at config 2's size).  x goes through a wave-private f32 LDS patch
-//     [pixel][16] (bank-conflict-free in both directions), B = the lane's tap (r < 9) of d_raw at pixel 4m + gq.
+//   weight gradient dW[ci][tap] = sum_pixel x[pixel][ci] * d[pixel (+) tap], K = the wave's 32 pixels: this conv feeds a BatchNorm, so its true
+//     weight gradient is the small remainder of terms that cancel ~1000-fold and plain bf16 operands leave nothing of it (rel-L2 1.95 at
+//     config 2's size).  Both operands are therefore split hi + lo (two bf16 each, ~2^-17 relative) and the product is three bf16
+//     MFMAs per wave and tile, xh dh + xh dl + xl dh (eight 16x16x4 f32 MFMAs give the same result and cost 70 us more: 256 vs 48 cycles of
+//     the matrix pipe per wave and tile).  x hi / lo go through two wave-private bf16 LDS patches [pixel][16] and come back channel-major
+//     (ds_read_b64_tr_b16); B = 8 consecutive d_raw values per lane (tap = r < 9).
 // Same tiles, d_raw staging, partial-row layouts and fixed summation order as the VALU form.
 __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, const float* __restrict__ ms, const float* __restrict__ mb,
                                                                   const float* __restrict__ ms1, const float* __restrict__ mb1,
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
   const int R = PT >> tg.wshift, pitch = W + 2, rows = R + 2;
   const int tile_floats = (rows * pitch + 3) & ~3;
   float* sD = smem;                                                    // [2][rows][pitch]
-  float* sX = smem + 2 * tile_floats;                                 // [4 waves][32 pixels][16 channels] f32
+  float* sX = smem + 2 * tile_floats;                                 // [4 waves][hi, lo][32 pixels][16 channels] bf16
   float* sR = sX + 4 * 512;                                           // [4][48] sums, [4][144] weight-gradient fragments
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
   const bool odd = gq & 1, lo_half = gq >= 2;
@@ -752,11 +754,12 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
     acc[0][j] = 0.f; acc[1][j] = 0.f; acc[2][j] = 0.f;
   }
   f32x4 macc = {0.f, 0.f, 0.f, 0.f};
-  float* sXw = sX + wv * 512;
+  char* sXw = reinterpret_cast<char*>(sX + wv * 512);
   const int p0 = 32 * wv, pr = p0 >> tg.wshift, c0 = p0 & (W - 1);     // the wave's 32 pixels: one row (W >= 32)
-  // weight gradient operands of K step m: A[ci = r][k = gq] = x[pixel 4m + gq][r]; B[k = gq][tap = r] = d_raw of that pixel shifted by the tap
+  // weight gradient operands: A = x^T out of the patches; B: lane (tap = r, k slice gq) reads d_raw of pixels c0 + 8gq .. + 7 shifted by its tap
+  const int a0 = (8 * gq + (r >> 2)) * 32 + (r & 3) * 8, a1 = a0 + 4 * 32;
   const int tw = r < 9 ? r : 8, twh = tw / 3, tww = tw - 3 * twh;
-  const int wofs = (pr + 2 - twh) * pitch + c0 + gq + 2 - tww;
+  const int wofs = (pr + 2 - twh) * pitch + c0 + 8 * gq + 2 - tww;
   const int stage = rows * W;
   int buf = 0;
   uint2 q0[2], q1[2];
@@ -818,13 +821,26 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
         const float gg = x[j] > 0.f ? g[j] : 0.f;
         acc[0][j] += gg; acc[1][j] += gg * f0[j]; acc[2][j] += gg * f1[j];
       }
-      *reinterpret_cast<float4*>(sXw + (16 * pt + r) * 16 + 4 * gq) = make_float4(x[0], x[1], x[2], x[3]);
+      const uint32_t h0 = pack2_bf16(x[0], x[1]), h1 = pack2_bf16(x[2], x[3]);
+      const uint32_t l0 = pack2_bf16(x[0] - __uint_as_float(h0 << 16), x[1] - __uint_as_float(h0 & 0xffff0000u));
+      const uint32_t l1 = pack2_bf16(x[2] - __uint_as_float(h1 << 16), x[3] - __uint_as_float(h1 & 0xffff0000u));
+      *reinterpret_cast<uint2*>(sXw + (16 * pt + r) * 32 + gq * 8) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(sXw + 1024 + (16 * pt + r) * 32 + gq * 8) = make_uint2(l0, l1);
     }
+    {
+      Vec16 bh, bl;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const float av = sXw[(4 * m + gq) * 16 + r];
-      const float dv = sT[wofs + 4 * m];
-      macc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, r < 9 ? dv : 0.f, macc, 0, 0, 0);
+      for (int k = 0; k < 4; ++k) {
+        const float d0 = sT[wofs + 2 * k], d1 = sT[wofs + 2 * k + 1];
+        const uint32_t hi = pack2_bf16(d0, d1);
+        const uint32_t lo = pack2_bf16(d0 - __uint_as_float(hi << 16), d1 - __uint_as_float(hi & 0xffff0000u));
+        bh.w[k] = r < 9 ? hi : 0u;
+        bl.w[k] = r < 9 ? lo : 0u;
+      }
+      const Vec16 ah = FragOps<bf16_t>::load(sXw, a0, a1), al = FragOps<bf16_t>::load(sXw + 1024, a0, a1);
+      macc = mma_bf16(ah, bh, macc);
+      macc = mma_bf16(ah, bl, macc);
+      macc = mma_bf16(al, bh, macc);
     }
   }
   // ---- block sums: the 16 pixel lanes of a row (DPP), then the four waves in order through LDS
