@@ -732,13 +732,14 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
   extern __shared__ float smem[];
   const int W = tg.W, H = tg.H, hw = H * W;
   const int R = PT >> tg.wshift, pitch = W + 2, rows = R + 2;
-  const int tile_floats = (rows * pitch + 3) & ~3;
-  float* sD = smem;                                                    // [2][rows][pitch]
-  float* sX = smem + 2 * tile_floats;                                 // [4 waves][hi, lo][32 pixels][16 channels] bf16
+  const int tile_floats = ((rows * pitch + 3) & ~3) + 8;               // + 8 zeros: where lanes without a tap read their operand
+  const int zoff = tile_floats - 8;
+  float* sD = smem;                                                    // [2 buffers][hi, lo][rows][pitch]: d_raw split at staging time
+  float* sX = smem + 4 * tile_floats;                                 // [4 waves][hi, lo][32 pixels][16 channels] bf16
   float* sR = sX + 4 * 512;                                           // [4][48] sums, [4][144] weight-gradient fragments
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 15, gq = lane >> 4;
   const bool odd = gq & 1, lo_half = gq >= 2;
-  for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;       // halo columns stay zero for the kernel's lifetime
+  for (int i = tid; i < 4 * tile_floats; i += 256) sD[i] = 0.f;       // halo columns stay zero for the kernel's lifetime
   // A of the data gradient: [ci = r][k = 8gq + t] = w[ci][tap = 8 (gq & 1) + t] (taps >= 9: zero), the same for the hi and the lo k range
   Vec16 wA;
 #pragma unroll
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
   // weight gradient operands: A = x^T out of the patches; B: lane (tap = r, k slice gq) reads d_raw of pixels c0 + 8gq .. + 7 shifted by its tap
   const int a0 = (8 * gq + (r >> 2)) * 32 + (r & 3) * 8, a1 = a0 + 4 * 32;
   const int tw = r < 9 ? r : 8, twh = tw / 3, tww = tw - 3 * twh;
-  const int wofs = (pr + 2 - twh) * pitch + c0 + 8 * gq + 2 - tww;
+  const int wofs = r < 9 ? (pr + 2 - twh) * pitch + c0 + 8 * gq + 2 - tww : zoff;
   const int stage = rows * W;
   int buf = 0;
   uint2 q0[2], q1[2];
@@ -782,12 +783,14 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
   __syncthreads();
   if ((int)blockIdx.x < tg.ntiles) fetch(blockIdx.x);
   for (int t = blockIdx.x; t < tg.ntiles; t += gridDim.x, buf ^= 1) {
-    float* sT = sD + buf * tile_floats;
+    float* sT = sD + buf * 2 * tile_floats;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int e = tid + k * 256, rr = e >> tg.wshift, c = e & (W - 1);
-      if (e < stage) sT[rr * pitch + c + 1] = dpre[k];
+      const float hi = __uint_as_float(pack2_bf16(dpre[k], 0.f) << 16);       // d = hi + lo, hi an exact bf16; lo is cut to bf16 when packed
+      if (e < stage) { sT[rr * pitch + c + 1] = hi; sT[tile_floats + rr * pitch + c + 1] = dpre[k] - hi; }
     }
+    const float* img = sT + (lo_half ? tile_floats : 0);
     uint2 c0v[2] = {q0[0], q0[1]}, c1v[2] = {q1[0], q1[1]};
     if (t + (int)gridDim.x < tg.ntiles) fetch(t + gridDim.x);
     __syncthreads();
@@ -796,19 +799,13 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
       const int base = (pr + 2) * pitch + c0 + 16 * pt + r + 2;
       // B[k = 8gq + t][pixel r]: taps 0..7 (even gq) / tap 8 in slot 0 (odd gq); hi parts (gq < 2) / lo parts (gq >= 2)
       float dv[8];
-      dv[0] = sT[base - (odd ? 2 * pitch + 2 : 0)];
+      dv[0] = img[base - (odd ? 2 * pitch + 2 : 0)];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) {
-        const float v = sT[base - (k / 3) * pitch - (k % 3)];
-        dv[k] = odd ? 0.f : v;
-      }
+      for (int k = 1; k < 8; ++k) dv[k] = img[odd ? zoff : base - (k / 3) * pitch - (k % 3)];
       Vec16 bf;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t hi = pack2_bf16(dv[2 * k], dv[2 * k + 1]);
-        const uint32_t lo = pack2_bf16(dv[2 * k] - __uint_as_float(hi << 16), dv[2 * k + 1] - __uint_as_float(hi & 0xffff0000u));
-        bf.w[k] = lo_half ? lo : hi;
-      }
+      for (int k = 0; k < 4; ++k)
+        bf.w[k] = __builtin_amdgcn_perm(__float_as_uint(dv[2 * k + 1]), __float_as_uint(dv[2 * k]), 0x07060302u);     // the two upper halves
       const f32x4 g = mma_bf16(wA, bf, (f32x4){0.f, 0.f, 0.f, 0.f});
       const float f0[4] = {__uint_as_float(c0v[pt].x << 16), __uint_as_float(c0v[pt].x & 0xffff0000u), __uint_as_float(c0v[pt].y << 16),
                            __uint_as_float(c0v[pt].y & 0xffff0000u)};
@@ -831,11 +828,8 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
       Vec16 bh, bl;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float d0 = sT[wofs + 2 * k], d1 = sT[wofs + 2 * k + 1];
-        const uint32_t hi = pack2_bf16(d0, d1);
-        const uint32_t lo = pack2_bf16(d0 - __uint_as_float(hi << 16), d1 - __uint_as_float(hi & 0xffff0000u));
-        bh.w[k] = r < 9 ? hi : 0u;
-        bl.w[k] = r < 9 ? lo : 0u;
+        bh.w[k] = __builtin_amdgcn_perm(__float_as_uint(sT[wofs + 2 * k + 1]), __float_as_uint(sT[wofs + 2 * k]), 0x07060302u);
+        bl.w[k] = __builtin_amdgcn_perm(__float_as_uint(sT[tile_floats + wofs + 2 * k + 1]), __float_as_uint(sT[tile_floats + wofs + 2 * k]), 0x07060302u);
       }
       const Vec16 ah = FragOps<bf16_t>::load(sXw, a0, a1), al = FragOps<bf16_t>::load(sXw + 1024, a0, a1);
       macc = mma_bf16(ah, bh, macc);
@@ -1005,7 +999,7 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
     if (wpartials && dt != DT_F32 && OC == 1 && W >= 32 && mfma_env) {
       const int nb = ntiles < 1024 ? ntiles : 1024;                  // four blocks per CU (114 VGPRs): one resident round (314 us; 768: 345, 512: 411)
       const int tf = ((pt / W + 2) * (W + 2) + 3) & ~3;
-      const size_t lds = ((size_t)2 * tf + 4 * 512 + 192 + 576) * sizeof(float);
+      const size_t lds = ((size_t)4 * (tf + 8) + 4 * 512 + 192 + 576) * sizeof(float);
       hipLaunchKernelGGL(tail_reduce_mfma_kernel, dim3(nb), dim3(256), lds, s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, (const bf16_t*)y1, partials, wpartials);
       const int rcm = check_launch("tail_reduce_mfma");
       return rcm ? rcm : nb;
