@@ -185,7 +185,7 @@ def dominant_kernel_roofline(M, device, N, reps=20):
 
 def largest_launch_roofline(M, device, N, reps=10):
     """Second roofline object: the single longest launch of the step, the last up-block's join-backward apply pass
-    (tail_join_bwd_kernel<bf16, apply>): reads the two branch outputs, recomputes the incoming gradient from the 1-plane
+    (tail_apply_mfma_kernel): reads the two branch outputs, recomputes the incoming gradient from the 1-plane
     d_raw, writes dy2 / dys.  Algorithmic bytes per launch = 4 x (N*64*64*16 bf16) + d_raw once (f32)."""
     L = importlib.import_module(PKG + "._lib")
     lib = L.lib()
@@ -218,7 +218,7 @@ def largest_launch_roofline(M, device, N, reps=10):
     traffic, src = pmc_traffic("uplayer5.join_bwd_apply", N)
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": src,
-            "kernel": "tail_join_bwd_kernel<bf16,apply> @ decoder.uplayer5 join backward fused with the decoder.conv2 dgrad (isolated launches)",
+            "kernel": "tail_apply_mfma_kernel @ decoder.uplayer5 join backward (apply pass) fused with the decoder.conv2 dgrad (isolated launches)",
             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
 
 
