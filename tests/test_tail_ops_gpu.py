@@ -125,7 +125,7 @@ def test_tail_join_fwd_stream(N):
 
 @pytest.mark.parametrize("wgrad", [False, True])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", SHAPES + [(2, 128, 128, 1)], ids=lambda s: "x".join(map(str, s)))     # + one-row tiles of the MFMA form
 def test_tail_join_bwd(shape, dt, wgrad):
     L = _lib()
     lib = L.lib()
