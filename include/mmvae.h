@@ -46,6 +46,9 @@ extern "C" {
                            weights (static power-of-two scale per layer, absorbed exactly by the BatchNorm) x e4m3 activations (quantised
                            behind the fused BN+ReLU), f32 accumulation and statistics; the backward pass stays bf16 (straight-through) */
 
+/* Version of this header's signatures.  2: mmvae_conv2d_wgrad gained the caller-owned `scratch` argument (before `stream`);
+ * a binding built against version 1 must not call version 2 (check mmvae_abi_version() == MMVAE_ABI_VERSION at load time). */
+#define MMVAE_ABI_VERSION 3
 MMVAE_API int mmvae_abi_version(void);
 MMVAE_API const char* mmvae_last_error(void);          /* host string, valid until the next failing call on this thread */
 
@@ -120,6 +123,12 @@ MMVAE_API int mmvae_comm_destroy(mmvae_comm* comm);
 /* SyncBN through the communicator instead of a host callback: the row all-reduces are enqueued in-stream by the library.
  * comm == NULL restores per-rank statistics. */
 MMVAE_API int mmvae_net_set_sync_bn_comm(mmvae_net* net, mmvae_comm* comm);
+/* The rows are issued from TWO streams (the caller's and the net's side stream, which carries the shortcut branches), and a third
+ * stream may carry the gradient buckets: RCCL orders the collectives of one communicator, so sharing one communicator would queue the
+ * encoder's SyncBN rows behind the decoder's gradient bucket and relies on RCCL serialising concurrent streams.  This form gives the
+ * rows of each stream a communicator of their own (both must differ from the one the gradient buckets use); on every rank each of
+ * them sees its collectives in program order.  comm_side == NULL: side-stream rows use comm_main as well (the one-communicator form). */
+MMVAE_API int mmvae_net_set_sync_bn_comm2(mmvae_net* net, mmvae_comm* comm_main, mmvae_comm* comm_side);
 
 /* ------------------------------------------------------------------ latent + loss (model.py:148-150, :364-406)
  * Reparameterisation  enc = mu + eps * exp(0.5*logvar)  (VAE_Encoder.rsample, model.py:148-150). */

@@ -368,9 +368,11 @@ __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a0, BnBwdFinalizeArgs a
     if (a.dbeta) a.dbeta[c] += (float)s0;
     const double m1 = s0 / a.count, m2 = sgy / a.count;
     const double A = g * istd;
-    a.coefA[c] = (float)A;
-    a.coefB[c] = (float)(-A * m2 * istd);
-    a.coefC[c] = (float)(-A * m1 + A * m2 * istd * mean);
+    const float Af = (float)A, Bf = (float)(-A * m2 * istd), Cf = (float)(-A * m1 + A * m2 * istd * mean);
+    a.coefA[c] = Af;
+    a.coefB[c] = Bf;
+    a.coefC[c] = Cf;
+    if (a.dbias_conv) a.dbias_conv[c] += (float)(((double)Af * s0 + (double)Bf * (mean * a.count) + (double)Cf * a.count) * (double)a.dbias_scale);
   }
 }
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s) {
@@ -1304,20 +1306,15 @@ int launch_affine_nchw(const float* raw, const float* scale, const float* shift,
   hipLaunchKernelGGL(affine_nchw_kernel, dim3(blocks), dim3(256), 0, s, raw, scale, shift, out, total, C, HW);
   return check_launch("affine_nchw");
 }
-// dy = A[c]*dout + B[c]*y + C[c] on NCHW f32 planes; optionally dbias[c] += sum(dy) (the bias gradient of the conv that
-// produced y).  Block = whole planes (n, c).
+// dy = A[c]*dout + B[c]*y + C[c] on NCHW f32 planes.  Block = whole planes (n, c).
 __global__ __launch_bounds__(256) void bn_bwd_apply_nchw_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                                 const float* __restrict__ A, const float* __restrict__ B,
                                                                 const float* __restrict__ Cc, float* __restrict__ dy, int planes, int C,
-                                                                int HW, float* __restrict__ dbias) {
-  __shared__ float sAcc[64];
-  if (threadIdx.x < 64) sAcc[threadIdx.x] = 0.f;
-  __syncthreads();
+                                                                int HW) {
   for (int p = blockIdx.x; p < planes; p += gridDim.x) {
     const int c = p % C;
     const float ca = A[c], cb = B[c], cc = Cc[c];
     const long base = (long)p * HW;
-    float s = 0.f;
     if ((HW & 3) == 0) {
       for (int i = threadIdx.x * 4; i < HW; i += 1024) {
         const float4 d = *reinterpret_cast<const float4*>(dout + base + i);
@@ -1325,26 +1322,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_nchw_kernel(const float* __r
         float4 o;
         o.x = ca * d.x + cb * v.x + cc; o.y = ca * d.y + cb * v.y + cc; o.z = ca * d.z + cb * v.z + cc; o.w = ca * d.w + cb * v.w + cc;
         *reinterpret_cast<float4*>(dy + base + i) = o;
-        s += (o.x + o.y) + (o.z + o.w);
       }
     } else {
-      for (int i = threadIdx.x; i < HW; i += 256) {
-        const float o = ca * dout[base + i] + cb * y[base + i] + cc;
-        dy[base + i] = o;
-        s += o;
-      }
+      for (int i = threadIdx.x; i < HW; i += 256) dy[base + i] = ca * dout[base + i] + cb * y[base + i] + cc;
     }
-    if (dbias) { s = wave_sum(s); if ((threadIdx.x & 63) == 0) atomicAdd(&sAcc[c], s); }
   }
-  __syncthreads();
-  if (dbias && threadIdx.x < C) atomicAdd(dbias + threadIdx.x, sAcc[threadIdx.x]);
 }
 int launch_bn_bwd_apply_nchw(const float* dout, const float* y, const float* A, const float* B, const float* Cc, float* dy,
-                             int N, int C, int HW, hipStream_t s, float* dbias) {
+                             int N, int C, int HW, hipStream_t s) {
   if (C > 64) { set_error("bn_bwd_apply_nchw: C=%d > 64", C); return MMVAE_ERR_UNSUPPORTED; }
   const int planes = N * C;
   const int blocks = planes < 4096 ? planes : 4096;
-  hipLaunchKernelGGL(bn_bwd_apply_nchw_kernel, dim3(blocks), dim3(256), 0, s, dout, y, A, B, Cc, dy, planes, C, HW, dbias);
+  hipLaunchKernelGGL(bn_bwd_apply_nchw_kernel, dim3(blocks), dim3(256), 0, s, dout, y, A, B, Cc, dy, planes, C, HW);
   return check_launch("bn_bwd_apply_nchw");
 }
 

@@ -16,7 +16,7 @@ static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
 
 extern "C" {
 
-int mmvae_abi_version(void) { return 1; }
+int mmvae_abi_version(void) { return MMVAE_ABI_VERSION; }
 const char* mmvae_last_error(void) { return last_error(); }
 
 int mmvae_net_create(mmvae_net** out, int in_channels, int z, int out_channels, int image_size, int need_logvar, int dtype) {
@@ -133,6 +133,11 @@ int mmvae_comm_destroy(mmvae_comm* c) {
 int mmvae_net_set_sync_bn_comm(mmvae_net* n, mmvae_comm* c) {
   if (!n) { set_error("net_set_sync_bn_comm: bad argument"); return MMVAE_ERR_ARG; }
   n->net->set_sync_bn_comm(c ? c->c : nullptr);
+  return MMVAE_OK;
+}
+int mmvae_net_set_sync_bn_comm2(mmvae_net* n, mmvae_comm* cm, mmvae_comm* cs) {
+  if (!n || (!cm && cs)) { set_error("net_set_sync_bn_comm2: bad argument"); return MMVAE_ERR_ARG; }
+  n->net->set_sync_bn_comm(cm ? cm->c : nullptr, cs ? cs->c : nullptr);
   return MMVAE_OK;
 }
 

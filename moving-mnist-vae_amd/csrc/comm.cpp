@@ -7,9 +7,11 @@
 // librccl.so; two copies in one process would each keep their own bootstrap state), else the system one.  Nothing here
 // needs RCCL at link or import time, so single-GPU users and the CPU-side symbol tests never load it.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 
 #include "comm.hpp"
@@ -30,13 +32,19 @@ struct Api {
   void* handle = nullptr;
   fn_get_uid get_uid = nullptr; fn_init_rank init_rank = nullptr; fn_allreduce allreduce = nullptr;
   fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
-  bool tried = false;
 };
 Api g_api;
+std::once_flag g_api_once;
+char g_api_error[256] = "";          // why the one resolution attempt failed (set_error's buffer is per thread: repeat it per caller)
 
+void resolve_api();
 const Api* api() {
-  if (g_api.tried) return g_api.handle ? &g_api : nullptr;
-  g_api.tried = true;
+  std::call_once(g_api_once, resolve_api);     // two threads creating communicators at once resolve the symbols exactly once
+  if (!g_api.handle) { set_error("%s", g_api_error); return nullptr; }
+  return &g_api;
+}
+
+void resolve_api() {
   const char* env = getenv("MMVAE_RCCL_LIB");
   const char* names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
@@ -46,19 +54,18 @@ const Api* api() {
       h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (h) break;
     }
-  if (!h) { set_error("comm: librccl.so not found (%s); set MMVAE_RCCL_LIB", dlerror()); return nullptr; }
+  if (!h) { snprintf(g_api_error, sizeof(g_api_error), "comm: librccl.so not found (%s); set MMVAE_RCCL_LIB", dlerror()); return; }
   g_api.get_uid = reinterpret_cast<fn_get_uid>(dlsym(h, "ncclGetUniqueId"));
   g_api.init_rank = reinterpret_cast<fn_init_rank>(dlsym(h, "ncclCommInitRank"));
   g_api.allreduce = reinterpret_cast<fn_allreduce>(dlsym(h, "ncclAllReduce"));
   g_api.destroy = reinterpret_cast<fn_destroy>(dlsym(h, "ncclCommDestroy"));
   g_api.errstr = reinterpret_cast<fn_errstr>(dlsym(h, "ncclGetErrorString"));
   if (!g_api.get_uid || !g_api.init_rank || !g_api.allreduce || !g_api.destroy) {
-    set_error("comm: RCCL symbols missing in the loaded library");
+    snprintf(g_api_error, sizeof(g_api_error), "comm: RCCL symbols missing in the loaded library");
     dlclose(h);
-    return nullptr;
+    return;
   }
   g_api.handle = h;
-  return &g_api;
 }
 
 int fail(const Api* a, const char* what, int rc) {

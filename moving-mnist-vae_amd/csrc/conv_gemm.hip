@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "kernels.hpp"
 
 namespace mmvae {
@@ -846,7 +848,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int aa = a0 + 16 * ta + 4 * g + j;
-          if (aa < a.Ca) atomicAdd(a.dW + (long)aa * a.sA + (long)bb * a.sB + a.tap_off[tap0 + tg], acc[i][j] * a.scale);
+          // partial image [pixel chunk = blockIdx.x][tap][a][b]: one owner per element, plain stores (summed by wgrad_reduce_kernel)
+          if (aa < a.Ca) a.scratch[(((long)blockIdx.x * a.ntaps + tap0 + tg) * a.Ca + aa) * a.Cb + bb] = acc[i][j];
         }
       }
     }
@@ -916,7 +919,8 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   static const int occ_env = [] { const char* e = getenv("MMVAE_WGRAD_OCC"); return e ? atoi(e) : 0; }();
   if (occ_env > 0) occ = occ_env;
   long gx = (256L * occ) / ((long)tiles_ab * zg); if (gx < 1) gx = 1;
-  const bool partial = a.scratch != nullptr;
+  if (!a.scratch) { set_error("wgrad: the partial-image scratch is required (no atomic flush path)"); return MMVAE_ERR_ARG; }
+  const bool partial = true;
   if (partial) {
     // keep the partial images (written once, read once) below the bytes of the operands themselves
     const long in_bytes = ((long)a.N * a.Hp * a.Wp * a.Ca + (long)a.N * a.Hg * a.Wg * a.Cb) * (long)dtype_size(dt);
@@ -948,6 +952,7 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   return 1;
 }
 
+#define MM_CHECK_RC(expr) do { const int rc__ = (expr); if (rc__ < 0) return rc__; } while (0)
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
   if (a.Ca % VE != 0 || a.Cb % VE != 0 || a.ntaps > 25 || a.ntaps < 1) {
@@ -979,10 +984,13 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   const int PK = KV * VE;
   const long ksteps = ((long)a.M + PK - 1) / PK;
   long want = 1024 / ((long)tiles * zg);               // pixel chunks so that ~1024 blocks exist
-  {                                                    // ...but keep the scattered global atomics below ~4M per launch
-    const long wsize = (long)a.Ca * a.Cb * a.ntaps;
-    long cap = (4L << 20) / (wsize > 0 ? wsize : 1);
-    if (cap < 2) cap = 2;
+  const long wsize = (long)a.Ca * a.Cb * a.ntaps;
+  if (!a.scratch) { set_error("wgrad: the partial-image scratch is required (no atomic flush path)"); return MMVAE_ERR_ARG; }
+  {                                                    // ...whose partial images fit the scratch (and stay below ~16M floats)
+    long cap = (long)(kWgradScratchBytes / 4) / (wsize > 0 ? wsize : 1);
+    const long cap2 = (16L << 20) / (wsize > 0 ? wsize : 1);
+    if (cap > cap2 && cap2 >= 8) cap = cap2;
+    if (cap < 1) { set_error("wgrad: one partial image (%ld floats) exceeds the scratch", wsize); return MMVAE_ERR_UNSUPPORTED; }
     if (want > cap) want = cap;
   }
   if (want < 1) want = 1;
@@ -993,7 +1001,12 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   dim3 grid(gx, tiles, zg), block(256);
   if (dt == DT_F32) hipLaunchKernelGGL((wgrad_kernel<float>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((wgrad_kernel<bf16_t>), grid, block, 0, s, a);
-  return check_launch("wgrad");
+  MM_CHECK_RC(check_launch("wgrad"));
+  WgradReduceArgs u; memset(&u, 0, sizeof(u));
+  u.part = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.nparts = gx;
+  u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid; u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
+  for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
+  return launch_wgrad_reduce(u, s);
 }
 
 // ============================================================================ weight packing
@@ -1056,7 +1069,7 @@ __global__ void pack_multi_kernel(PackMulti m) {
 
 static thread_local bool g_pack_batching = false;
 static thread_local int g_pack_n = 0;
-static thread_local PackJob g_pack_jobs[256];
+static thread_local std::vector<PackJob> g_pack_jobs;     // grows with the net (blocks_per_stage), never shrinks
 
 void pack_batch_begin() { g_pack_batching = true; g_pack_n = 0; }
 
@@ -1080,7 +1093,8 @@ int launch_pack(int dt, const PackArgs& a, hipStream_t s) {
   const long total = (long)a.cols * a.ntaps * a.K;
   if (total <= 0) return MMVAE_OK;
   if (g_pack_batching) {
-    if (g_pack_n >= 256 || a.ntaps > 26) { set_error("pack batch overflow"); return MMVAE_ERR_ARG; }
+    if (a.ntaps > 26) { set_error("pack: %d taps > 26", a.ntaps); return MMVAE_ERR_ARG; }
+    if ((size_t)g_pack_n >= g_pack_jobs.size()) g_pack_jobs.resize(g_pack_jobs.size() + 256);
     PackJob& j = g_pack_jobs[g_pack_n++];
     j.src = a.src; j.dst = a.dst; j.cols = a.cols; j.K = a.K; j.ntaps = a.ntaps; j.s_col = a.s_col; j.s_k = a.s_k;
     j.cols_valid = a.cols_valid; j.K_valid = a.K_valid; j.scale = a.scale; j.fp8 = (unsigned char)(a.fp8 ? 1 : 0); j.frag = (unsigned char)(a.frag ? 1 : 0);

@@ -69,19 +69,23 @@ static bool frag_enabled() {
   static const bool v = [] { const char* e = getenv("MMVAE_DEEP2_FRAG"); return !(e && e[0] == '0'); }();
   return v;
 }
-int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl, int fp8) {
-  if (!frag_enabled()) return 0;
+// does deep2_conv_kernel take this conv's down / up form at this place (large-side map Hl x Wl)?  fp8: its e4m3 form
+int op_deep2_down_ok(int dt, const ConvGeom& g, int Hl, int Wl, int fp8) {
   const int Hs = conv_down_size(Hl, g.k, g.s, g.p), Ws = conv_down_size(Wl, g.k, g.s, g.p);
   return deep2_shape_ok(dt, g.D1, g.D0, Hs, Ws, Hl, Wl, g.k * g.k, fp8) ? 1 : 0;
 }
-int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases, int fp8) {
-  if (!frag_enabled() || g.s > 2 || g.k * g.k > kMaxTaps) return 0;
+int op_deep2_up_ok(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases, int fp8) {
+  if (g.s > 2 || g.k * g.k > kMaxTaps) return 0;
   const int Hs = conv_down_size(Hl, g.k, g.s, g.p), Ws = conv_down_size(Wl, g.k, g.s, g.p);
   UpPhase ph[4];
   const int np = up_phases(g.k, g.s, g.p, ph);
   int ntaps = 0;
   for (int i = 0; i < np; ++i) { if (ph[i].ntaps == 0 && !allow_empty_phases) return 0; ntaps += ph[i].ntaps; }
   return deep2_shape_ok(dt, g.D0, g.D1, (Hl + g.s - 1) / g.s, (Wl + g.s - 1) / g.s, Hs, Ws, ntaps, fp8) ? 1 : 0;
+}
+int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl, int fp8) { return frag_enabled() ? op_deep2_down_ok(dt, g, Hl, Wl, fp8) : 0; }
+int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases, int fp8) {
+  return frag_enabled() ? op_deep2_up_ok(dt, g, Hl, Wl, allow_empty_phases, fp8) : 0;
 }
 
 int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N, const void* L, int Hl, int Wl, void* S, int Hs, int Ws,

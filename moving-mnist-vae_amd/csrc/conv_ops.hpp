@@ -18,6 +18,9 @@ inline int conv_down_size(int H, int k, int s, int p) { return (H + 2 * p - k) /
 int op_pack_down(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0, int frag = 0);
 int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t s, float scale = 1.f, int fp8 = 0, int frag = 0);
 int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl, int fp8 = 0);
+// the same geometry test without the MMVAE_DEEP2_FRAG developer switch: does deep2_conv_kernel (fp8: its e4m3 form) take this launch?
+int op_deep2_down_ok(int dt, const ConvGeom& g, int Hl, int Wl, int fp8 = 0);
+int op_deep2_up_ok(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases = 0, int fp8 = 0);
 // allow_empty_phases: the launch accumulates (or is a second source), so stride phases without a tap are skipped, not zero-filled
 int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases = 0, int fp8 = 0);
 // x2 / w2 / Cin2 (optional): a second tensor on the q grid (= S for run_down, = the S-resolution grid for run_up) whose 1x1

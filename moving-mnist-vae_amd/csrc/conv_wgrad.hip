@@ -35,62 +35,85 @@ int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int
   return dt == DT_F32 ? launch_wgrad2_f32(a, grid, ta16, tb16, slots, s) : launch_wgrad2_bf16(a, grid, ta16, tb16, slots, s);
 }
 
-// dW[a*sA + b*sB + tap_off[t]] += scale * sum_{p < nparts} part[p][t][a][b]
-// Block = 256 consecutive elements x one chunk of parts: lane l of every wave owns the float4 column l, wave w sums the
-// parts w, w+4, ... of the chunk (8 loads in flight), the four waves combine through LDS.  grid = (wsize/256, chunks);
-// with one chunk (large gradients) the result is added with a plain read-modify-write, else with float atomics.
+// dW[a*sA + b*sB + tap_off[t]] += scale * sum_{p < nparts} part[p][t][a][b]      -- no atomics, fixed summation order
+// A block owns E = 4*LANES consecutive elements of the image and ALL parts of them: thread (rg, l) sums the float4 column l of the
+// parts rg, rg + RG, ... (four independent accumulators, 16-byte loads), the RG row groups are combined by a fixed binary tree in
+// LDS, row group 0 adds the result into the weight layout with a plain read-modify-write (it is the only writer of its elements).
+// LANES is chosen from the image size alone (>= ~256 blocks where the image allows), so the order of every addition is a function of
+// the shapes: the same inputs give the same bits.  Taps that share a destination (the encoder heads: the 2x2 pooled positions all
+// accumulate into one 1x1 weight) are folded into the part axis by the launcher ([part][tap] is contiguous).
+template <int LANES>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
-  __shared__ float4 sSum[4][64];
+  constexpr int RG = 256 / LANES;
+  __shared__ float4 sSum[256];
   const int ab = a.Ca * a.Cb;
-  const int wsize = a.ntaps * ab;                 // multiple of 256 (Ca, Cb multiples of 16)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int per = (a.nparts + gridDim.y - 1) / gridDim.y;
-  const int p0 = blockIdx.y * per, p1 = min(a.nparts, p0 + per);
-  const float* src = a.part + (long)blockIdx.x * 256 + lane * 4;
+  const long wsize = (long)a.ntaps * ab;
+  const int l = threadIdx.x % LANES, rg = threadIdx.x / LANES;
+  const float* src = a.part + (long)blockIdx.x * (4 * LANES) + l * 4;
   float4 s[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  int p = p0 + wv;
-  for (; p + 12 < p1; p += 16) {
+  int p = rg;
+  for (; p + 3 * RG < a.nparts; p += 4 * RG) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(src + (long)(p + 4 * k) * wsize);
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)(p + k * RG) * wsize);
       s[k].x += v.x; s[k].y += v.y; s[k].z += v.z; s[k].w += v.w;
     }
   }
-  for (; p < p1; p += 4) {
+  for (; p < a.nparts; p += RG) {
     const float4 v = *reinterpret_cast<const float4*>(src + (long)p * wsize);
     s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
   }
-  sSum[wv][lane] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
-                               (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+  sSum[threadIdx.x] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                                  (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
   __syncthreads();
-  const float* f = reinterpret_cast<const float*>(sSum);
-  const int j = threadIdx.x;
-  const float sum = (f[j] + f[256 + j]) + (f[512 + j] + f[768 + j]);
-  const int i = blockIdx.x * 256 + j;
-  const int t = i / ab, rem = i - t * ab;
-  const int aa = rem / a.Cb, bb = rem - aa * a.Cb;
-  if (p1 > p0 && aa < a.Ca_valid && bb < a.Cb_valid) {
-    float* dst = a.dW + (long)aa * a.sA + (long)bb * a.sB + a.tap_off[t];
-    if (a.exclusive) *dst += sum * a.scale;
-    else atomicAdd(dst, sum * a.scale);
+#pragma unroll
+  for (int st = RG / 2; st >= 1; st >>= 1) {
+    if (rg < st) {
+      const float4 o = sSum[threadIdx.x + st * LANES];
+      float4& m = sSum[threadIdx.x];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+    }
+    __syncthreads();
+  }
+  if (rg == 0) {
+    const float4 m = sSum[l];
+    const float v[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long i = (long)blockIdx.x * (4 * LANES) + l * 4 + j;
+      const int t = (int)(i / ab), rem = (int)(i - (long)t * ab);
+      const int aa = rem / a.Cb, bb = rem - aa * a.Cb;
+      if (aa < a.Ca_valid && bb < a.Cb_valid) a.dW[(long)aa * a.sA + (long)bb * a.sB + a.tap_off[t]] += v[j] * a.scale;
+    }
   }
 }
 
 int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s) {
-  const int wsize = a.ntaps * a.Ca * a.Cb;
-  if (wsize % 256) { set_error("wgrad_reduce: %d elements not a multiple of 256", wsize); return MMVAE_ERR_ARG; }
-  const int bx = wsize / 256;
-  int gy = (512 + bx - 1) / bx;                  // >= ~512 blocks ...
-  if (gy > a.nparts / 16) gy = a.nparts / 16;    // ... of >= 16 parts (4 per wave) each
-  if (gy < 1) gy = 1;
-  // one chunk and distinct destinations (no two taps share a weight): plain read-modify-write
+  if (a.nparts < 1) return MMVAE_OK;
+  // taps that share a destination become extra parts of a one-tap image (all of them must then share it)
   bool distinct = true;
   for (int t = 0; t < a.ntaps && distinct; ++t)
     for (int u = 0; u < t; ++u) if (a.tap_off[u] == a.tap_off[t]) { distinct = false; break; }
-  a.exclusive = (gy == 1 && distinct) ? 1 : 0;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, gy), dim3(256), 0, s, a);
+  if (!distinct) {
+    for (int t = 1; t < a.ntaps; ++t)
+      if (a.tap_off[t] != a.tap_off[0]) { set_error("wgrad_reduce: taps share some destinations but not all"); return MMVAE_ERR_UNSUPPORTED; }
+    a.nparts *= a.ntaps; a.ntaps = 1;
+  }
+  const long wsize = (long)a.ntaps * a.Ca * a.Cb;
+  if (wsize % 256) { set_error("wgrad_reduce: %ld elements not a multiple of 256", wsize); return MMVAE_ERR_ARG; }
+  a.exclusive = 1;
+  // elements per block: 256 .. 32 (whole 128-byte lines per part), aiming at >= 256 blocks
+  int lanes = 64;
+  while (lanes > 8 && wsize / (4 * lanes) < 256) lanes >>= 1;
+  const dim3 grid((unsigned)(wsize / (4 * lanes)));
+  switch (lanes) {
+    case 64: hipLaunchKernelGGL(wgrad_reduce_kernel<64>, grid, dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL(wgrad_reduce_kernel<32>, grid, dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL(wgrad_reduce_kernel<16>, grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(wgrad_reduce_kernel<8>, grid, dim3(256), 0, s, a); break;
+  }
   return check_launch("wgrad_reduce");
 }
 

@@ -251,6 +251,10 @@ int launch_bn_bwd_reduce(int dt, const void* dout, const void* out, const float*
 struct BnBwdFinalizeArgs {
   const float* partials; int nparts; int C; int which /*0: y0, 1: y1*/; int ny; double count;
   const float* gamma; const float* mean; const float* istd; float* dgamma; float* dbeta; float* coefA; float* coefB; float* coefC;
+  // optional: bias gradient of the conv that feeds this BatchNorm, dbias[c] += dbias_scale * sum(dy) = A sum(g) + B sum(y) + C count
+  // in closed form from the sums at hand (analytically zero: a bias in front of a BatchNorm has no gradient; what is left is the
+  // rounding of the coefficients) -- no pass over dy, no atomics
+  float* dbias_conv = nullptr; float dbias_scale = 1.f;
 };
 int launch_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
 int launch_bn_bwd_finalize2(const BnBwdFinalizeArgs& a0, const BnBwdFinalizeArgs& a1, hipStream_t s);   // two BNs of equal width, one launch
@@ -278,7 +282,7 @@ int launch_tail_join_fwd(int dt, const void* y0, const float* ms, const float* m
 int launch_affine_nchw(const float* raw, const float* scale, const float* shift, float* out, int N, int C, int HW, hipStream_t s);
 int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s);
 int launch_bn_bwd_apply_nchw(const float* dout, const float* y, const float* A, const float* B, const float* Cc, float* dy,
-                             int N, int C, int HW, hipStream_t s, float* dbias = nullptr);
+                             int N, int C, int HW, hipStream_t s);
 
 // ---------------------------------------------------------------- latent / loss
 // enc = mu + exp(0.5*logvar)*eps (f32 and T copies); kl_partial: -0.5*sum(lv - exp(lv) - mu^2 + 1) (one float, atomically added)

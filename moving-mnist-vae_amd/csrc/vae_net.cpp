@@ -34,12 +34,22 @@ ConvW Net::add_conv(const std::string& name, int D0, int D1, int k, int s, int p
   if (numel > max_w) max_w = numel;
   if (pack) { w.packD = n_packed; n_packed += align_up(numel, 8); w.packU = n_packed; n_packed += align_up(numel, 8); }
   if (cfg.fp8 && pack && D0 >= 64 && D1 >= 64 && D0 % 64 == 0 && D1 % 64 == 0) {
+    // candidate; settle_fp8() confirms it once the layer's place in the net (Hl) is known
     // static scale: PyTorch's default init is U(+-1/sqrt(D1*k*k)) for both weight layouts; bring that bound to ~16..32 (e4m3 normal range)
     w.fp8 = true;
     int e = 0; while ((float)(1 << e) < 16.f * std::sqrt((float)D1 * k * k)) ++e;
     w.wscale = (float)(1 << e);
   }
   return w;
+}
+
+// An fp8 layer's forward weights are e4m3 bytes that only the fp8 form of deep2_conv_kernel reads: keep the flag only where that kernel
+// takes the layer's FORWARD launch (e.g. z = 192 makes decoder.conv1 a 3-chunk row, which it does not) -- the others stay bf16 layers.
+void Net::settle_fp8(ConvW& w) const {
+  if (!w.fp8) return;
+  const bool ok = w.Hl > 0 && (w.tr ? op_deep2_up_ok(DT_BF16, ConvGeom{w.D0, w.D1, w.k, w.s, w.p}, w.Hl, w.Hl, 1, 1)
+                                    : op_deep2_down_ok(DT_BF16, ConvGeom{w.D0, w.D1, w.k, w.s, w.p}, w.Hl, w.Hl, 1));
+  if (!ok) { w.fp8 = false; w.wscale = 1.f; }
 }
 
 Bn Net::add_bn(const std::string& prefix, int C) {
@@ -132,6 +142,9 @@ Net::Net(const NetCfg& c) : cfg(c) {
     }
   }
   Sd = H;
+  settle_fp8(dstem);
+  for (Block& B : enc) { settle_fp8(B.c1); settle_fp8(B.c2); settle_fp8(B.cs); }
+  for (Block& B : dec) { settle_fp8(B.c1); settle_fp8(B.c2); settle_fp8(B.cs); }
   tail = add_conv("decoder.conv2.weight", c.out_ch, 16, 3, 1, 1, false);
   tail_bias = n_params; add_entry("decoder.conv2.bias", {c.out_ch}, EK_PARAM, n_params); n_params += c.out_ch;
   bn_out = add_bn("decoder.bn2", c.out_ch);
@@ -303,7 +316,7 @@ int Net::sync_rows(char* base, const float* partials, int nparts, int width, hip
   if (width > 1024) { set_error("sync_bn: %d statistics per BatchNorm > 1024", width); return MMVAE_ERR_UNSUPPORTED; }
   float* buf = reinterpret_cast<float*>(base + plan_.syncbuf) + (s == side_ ? 1024 : 0);
   MM_TRY(launch_partial_rowsum(partials, nparts, width, buf, s, row_stride));
-  if (comm_) MM_TRY(comm_allreduce_sum(comm_, buf, width, s));
+  if (comm_) MM_TRY(comm_allreduce_sum((s == side_ && comm_side_) ? comm_side_ : comm_, buf, width, s));
   else if (ar_fn_(buf, width, s, ar_user_) != 0) { set_error("sync_bn: the all-reduce callback failed"); return MMVAE_ERR_ARG; }
   *out = buf;
   return MMVAE_OK;
@@ -346,14 +359,18 @@ BnBwdFinalizeArgs Net::bwd_finalize_args(const Bn& bn, const float* params, floa
 // dx = A*g + B*y + C use the sums over the global batch -- so the local finalize runs first and a second one, fed with the
 // all-reduced row, overwrites the coefficients.
 int Net::bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
-                           hipStream_t s) {
+                           hipStream_t s, float* dbias_conv) {
   const float* part = reinterpret_cast<const float*>(base + plan_.partials);
-  MM_TRY(launch_bn_bwd_finalize(bwd_finalize_args(bn, params, grads, base, part, nparts, ny, which, count), s));
+  BnBwdFinalizeArgs l = bwd_finalize_args(bn, params, grads, base, part, nparts, ny, which, count);
+  if (!sync_bn_on()) l.dbias_conv = dbias_conv;
+  MM_TRY(launch_bn_bwd_finalize(l, s));
   if (!sync_bn_on()) return MMVAE_OK;
   float* row = nullptr;
   MM_TRY(sync_rows(base, part, nparts, (1 + ny) * bn.C, s, &row));
   BnBwdFinalizeArgs g = bwd_finalize_args(bn, params, grads, base, row, 1, ny, which, count * ar_world_);
   g.dgamma = nullptr; g.dbeta = nullptr;
+  // the gradient all-reduce sums the ranks: every rank contributes 1/world of the global closed form
+  g.dbias_conv = dbias_conv; g.dbias_scale = 1.f / (float)ar_world_;
   return launch_bn_bwd_finalize(g, s);
 }
 // the two BatchNorms of a residual join (partials rows: sum g, sum g*y2, sum g*ys) in one launch
@@ -833,10 +850,9 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   // ---- output BN backward, tail conv backward
   int np = launch_bn_bwd_reduce_nchw(d_recon, r_raw, N, cfg.out_ch, HW, part, s);
   MM_TRY(np);
-  MM_TRY(bn_backward_coefs(bn_out, params, grads, base, np, 1, 0, (double)N * HW, s));
-  // (the tail conv's bias gradient, sum of d_raw per output channel, comes out of the same pass)
-  MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s,
-                                  grads + tail_bias));
+  // (the tail conv's bias gradient, sum of d_raw per output channel, in closed form from the same sums: BnBwdFinalizeArgs::dbias_conv)
+  MM_TRY(bn_backward_coefs(bn_out, params, grads, base, np, 1, 0, (double)N * HW, s, grads + tail_bias));
+  MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
   static const bool tail_wgrad_direct = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_DIRECT"); return e && e[0] == '1'; }();
   // one output plane: a tiled VALU reduction (launch_tail_wgrad_tile) beats the MFMA wgrad; MMVAE_TAIL_WGRAD_TILE=0 disables it
   static const bool tail_wgrad_tile_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_TILE"); return !(e && e[0] == '0'); }();

@@ -104,6 +104,7 @@ class Net {
   int dt() const { return cfg.dtype; }
   size_t esz() const { return dtype_size(cfg.dtype); }
   ConvW add_conv(const std::string& name, int D0, int D1, int k, int s, int p, bool pack, bool transposed = false);
+  void settle_fp8(ConvW& w) const;
   Bn add_bn(const std::string& prefix, int C);
   void add_entry(const std::string& name, std::initializer_list<int> shape, int kind, long off);
 
@@ -132,15 +133,16 @@ class Net {
   // decoder_bwd leaves its weight gradients running on the side stream; encoder_bwd (or join()) orders them before the caller's stream
   bool defer_join_ = false;
   int (*ar_fn_)(float*, long long, void*, void*) = nullptr; void* ar_user_ = nullptr; int ar_world_ = 1;
-  Comm* comm_ = nullptr;
+  Comm* comm_ = nullptr; Comm* comm_side_ = nullptr;
   int sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out, int row_stride = 0);
  public:
   void set_defer_join(bool v) { defer_join_ = v; }
   // SyncBN: fn sums a device f32 buffer over all ranks, ordered on the given stream; NULL = per-rank statistics
   typedef int (*AllReduceFn)(float* buf, long long n, void* stream, void* user);
-  void set_sync_bn(AllReduceFn fn, void* user, int world) { ar_fn_ = fn; ar_user_ = user; ar_world_ = fn ? world : 1; comm_ = nullptr; }
+  void set_sync_bn(AllReduceFn fn, void* user, int world) { ar_fn_ = fn; ar_user_ = user; ar_world_ = fn ? world : 1; comm_ = comm_side_ = nullptr; }
   // SyncBN through an RCCL communicator of this library: the row all-reduce is enqueued in-stream (no host callback, capturable)
-  void set_sync_bn_comm(Comm* c) { comm_ = c; ar_fn_ = nullptr; ar_user_ = nullptr; ar_world_ = c ? comm_world(c) : 1; }
+  // (side: the communicator of the rows issued on the side stream; null = the same one)
+  void set_sync_bn_comm(Comm* c, Comm* side = nullptr) { comm_ = c; comm_side_ = c ? side : nullptr; ar_fn_ = nullptr; ar_user_ = nullptr; ar_world_ = c ? comm_world(c) : 1; }
   bool sync_bn_on() const { return ar_fn_ != nullptr || comm_ != nullptr; }
   int join(hipStream_t s) { return side_join(s); }
  private:
@@ -152,7 +154,7 @@ class Net {
   const float* zeros(char* base) const { return reinterpret_cast<const float*>(base + plan_.cvec) + 256; }
   int fill_consts(char* base, hipStream_t s);
   int bn_backward_coefs(const Bn& bn, const float* params, float* grads, char* base, int nparts, int ny, int which, double count,
-                        hipStream_t s);
+                        hipStream_t s, float* dbias_conv = nullptr);
   BnBwdFinalizeArgs bwd_finalize_args(const Bn& bn, const float* params, float* grads, char* base, const float* partials, int nparts, int ny,
                                       int which, double count) const;
   int bn_backward_coefs_join(const Bn& b2, const Bn& bs, const float* params, float* grads, char* base, int nparts, double count, hipStream_t s);

@@ -145,7 +145,10 @@ def select_model(args):
                 z_dimension=mp["z_dimension"], pixelcnn=False, only_pixelcnn=False,
                 pixelcnn_layers=mp["num_pixelcnn_layers"], pixelcnn_activation=mp["pixelcnn_activation"],
                 nll=mp["coeff_nll"], kl=mp["coeff_kl"], mmd=mp["coeff_mmd"], require_rsample=mp["require_rsample"],
-                sigma_decoder=mp["sigma_decoder"], input_image_size=mp["input_image_size"])
+                sigma_decoder=mp["sigma_decoder"], input_image_size=mp["input_image_size"],
+                compute_dtype=getattr(args, "compute_dtype", None), blocks_per_stage=int(getattr(args, "blocks_per_stage", 1)))
+    # build-defined extensions ride along in the parameter dict (and from there into the checkpoint)
+    mp["compute_dtype"], mp["blocks_per_stage"] = model.compute_dtype, model.blocks_per_stage
     return model, mp
 
 
@@ -155,14 +158,33 @@ def save_checkpoint(model, optimizer, epoch, directory):
     import os
     os.makedirs(directory, exist_ok=True)
     path = os.path.join(directory, "latest-model.model")
-    torch.save({"epoch": epoch, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}, path)
+    ck = {"epoch": epoch, "state_dict": model.state_dict(), "optimizer": optimizer.state_dict()}
+    # the reference network keeps the reference's three keys; a build-defined variant (deeper net, fp8 compute mode) adds what a loader
+    # needs to rebuild it
+    blocks, cdt = int(getattr(model, "blocks_per_stage", 1)), getattr(model, "compute_dtype", None)
+    if blocks != 1 or cdt == "fp8":
+        ck["mmvae"] = {"compute_dtype": cdt, "blocks_per_stage": blocks}
+    torch.save(ck, path)
     return path
+
+
+def checkpoint_variant(path, map_location=None):
+    """The build-defined constructor keywords a checkpoint was saved with: {'compute_dtype', 'blocks_per_stage'} (reference
+    checkpoints, which lack the entry: the reference network, default compute mode)."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    v = dict(ck.get("mmvae") or {})
+    return {"compute_dtype": v.get("compute_dtype"), "blocks_per_stage": int(v.get("blocks_per_stage", 1))}
 
 
 def load_checkpoint(path, model, optimizer=None, map_location=None):
     """The resume path the reference lacks: restores parameters / BN buffers (and Adam moments for FusedAdam or
     torch.optim.Adam); returns the stored epoch."""
     ck = torch.load(path, map_location=map_location, weights_only=False)
+    want = int((ck.get("mmvae") or {}).get("blocks_per_stage", 1))
+    have = int(getattr(model, "blocks_per_stage", 1))
+    if want != have:
+        raise ValueError(f"checkpoint was saved from a net with blocks_per_stage={want}, the model has {have} "
+                         "(build it with checkpoint_variant(path)['blocks_per_stage'])")
     model.load_state_dict(ck["state_dict"])
     if optimizer is not None and "optimizer" in ck:
         loader = getattr(optimizer, "load_flat_state", None)

@@ -654,7 +654,30 @@ class FusedAdam(torch.optim.Optimizer):
             for (_, p, off, n, shp) in model._ptable:
                 self.state[p] = {"step": torch.tensor(float(self._t)), "exp_avg": self._m[off:off + n].view(shp),
                                  "exp_avg_sq": self._v[off:off + n].view(shp)}
+        if self._capturable and (self._step_dev is None or self._step_dev.device != flat.device):
+            # the device-side step counter is created HERE, outside step(): the first step() may run inside torch.cuda.graph, and
+            # an allocation + fill captured there would reset the counter on every replay
+            self._step_dev = torch.full((1,), float(self._t), dtype=torch.float64, device=flat.device)
         return self._m, self._v
+
+    def prepare_capture(self):
+        """Allocate the moments and the device-side step counter now (call once before capturing a step in a HIP graph)."""
+        model = self._model()
+        model._ensure_flat()
+        self._moments(model)
+        return self
+
+    def _sync_step_from_device(self):
+        """capturable: the authoritative step count lives on the device (graph replays advance it without the host seeing
+        a step() call); read it back -- one small D2H copy -- whenever the host needs it (state_dict, resume)."""
+        if self._capturable and self._step_dev is not None:
+            self._t = int(round(float(self._step_dev.item())))
+            for st_ in self.state.values():
+                st_["step"] = torch.tensor(float(self._t))
+
+    def state_dict(self):
+        self._sync_step_from_device()
+        return super().state_dict()
 
     def _flat_grads(self, model):
         first, last = model._ptable[0][1], model._ptable[-1][1]
@@ -688,6 +711,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._t = int(float(e["step"]))
         for st_ in self.state.values():
             st_["step"] = torch.tensor(float(self._t))
+        if self._step_dev is not None:            # capturable: the device counter follows the restored count (in place: a captured
+            self._step_dev.fill_(float(self._t))  # graph keeps pointing at this tensor)
         if state_dict.get("param_groups"):
             g = state_dict["param_groups"][0]
             for k in ("lr", "betas", "eps", "weight_decay"):
@@ -710,12 +735,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._t += 1
         b1, b2 = g["betas"]
         if self._capturable:
-            if self._step_dev is None or self._step_dev.device != model._flat.device:
-                self._step_dev = torch.full((1,), float(self._t - 1), dtype=torch.float64, device=model._flat.device)
             check(lib().mmvae_adam_step_dev(ptr(model._flat), ptr(G), ptr(m), ptr(v), model._n_params, float(g["lr"]), float(b1), float(b2),
                                             float(g["eps"]), float(g["weight_decay"]), ptr(self._step_dev), scale, _stream()),
                   "mmvae_adam_step_dev")
-            return loss            # (state["step"] mirrors the host count of step() calls; under graph replay read _step_dev)
+            # state[p]["step"] is refreshed from the device counter in state_dict(): under graph replay the host does not see the steps
+            return loss
         bc1 = 1.0 - b1 ** self._t
         bc2s = math.sqrt(1.0 - b2 ** self._t)
         check(lib().mmvae_adam_step(ptr(model._flat), ptr(G), ptr(m), ptr(v), model._n_params, float(g["lr"]), float(b1), float(b2),
@@ -800,8 +824,13 @@ class GradSync:
                 raise ValueError("comm must be 'torch', 'rccl' or a Communicator")
             comm = Communicator.from_torch_distributed(group) if comm == "rccl" else None
         self.comm = comm
+        self._bn_comms = ()
         if sync_bn and self.comm is not None:
-            check(lib().mmvae_net_set_sync_bn_comm(model._h, self.comm._h), "mmvae_net_set_sync_bn_comm")
+            # the SyncBN rows get communicators of their own, one per stream they are issued from (caller's stream, library side
+            # stream): RCCL orders the collectives of ONE communicator, so sharing the bucket communicator would queue the encoder's
+            # rows behind the decoder's gradient bucket and lean on RCCL serialising concurrent streams (mmvae.h)
+            self._bn_comms = (Communicator.from_torch_distributed(group), Communicator.from_torch_distributed(group))
+            check(lib().mmvae_net_set_sync_bn_comm2(model._h, self._bn_comms[0]._h, self._bn_comms[1]._h), "mmvae_net_set_sync_bn_comm2")
         elif sync_bn:
             model._ensure_flat()
 

@@ -186,3 +186,56 @@ def test_train_step_is_hipgraph_capturable_and_replays_the_eager_trajectory(orac
         den += float(((p_eager[k] - p0[k]).double() ** 2).sum())
     assert num <= (0.02 ** 2) * den, (num, den)
     print(f"\ngraph replay vs eager: losses {replayed} vs {eager}; max parameter difference {worst:.3e} (eager vs eager: {max(spread.values()):.3e})")
+
+
+@pytest.mark.parametrize("dtype,categorical", [("f32", False), ("bf16", False), ("bf16", True)])
+def test_train_step_is_bit_reproducible(oracle, dtype, categorical):
+    """include/mmvae.h: no reduction of the train step ends in a float atomic -- partial images / partial rows are summed in a fixed
+    order -- so the same step on the same inputs gives the same BITS: loss, every parameter gradient, the BatchNorm running statistics
+    and the parameters after Adam.  The second run starts from a NaN-poisoned workspace and gradient buffer (a kernel that read
+    memory it had not written, or summed in launch-timing order, would show), and a dummy kernel load on another stream shifts the
+    timing of the library's side stream."""
+    import types
+    M = _M()
+    main = importlib.import_module("moving-mnist-vae_amd.main")
+    dev = torch.device("cuda")
+    N, z = 48, 32
+    labels = oracle.synthetic_labels(N, 64, seed=77).to(dev)
+    g = torch.Generator().manual_seed(4)
+    eps, ts = torch.randn(N, z, 1, 1, generator=g).to(dev), torch.randn(N, z, generator=g).to(dev)
+    args = types.SimpleNamespace(data_ratio_of_labels=torch.tensor([0.0521, 0.9479]) if categorical else None, dataset="MovingMNIST", quiet=True)
+
+    def run(poison):
+        torch.manual_seed(5)
+        m = M.VAE(1, 32, 2 if categorical else 1, 2, z, False, False, 4, "ReLu", 1, 1, 10 if not categorical else 0, True, 0.1, 64,
+                  compute_dtype=dtype).to(dev).train()
+        opt = M.FusedAdam(list(m.parameters()))
+        m.injected_eps, m.injected_true_samples = eps, ts
+        if poison:
+            # allocate the workspace and both gradient buffers now and fill them with NaN; keep the second stream busy
+            m._workspace(N, True).view(torch.float32).fill_(float("nan"))
+            for i in (0, 1):
+                m._G[i] = torch.full((m._n_params,), float("nan"), device=dev)
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                junk = torch.randn(4096, 4096, device=dev)
+                for _ in range(20):
+                    junk = junk @ junk * 1e-3
+        image, target = main.prepare_batch(m, labels, dev, args, oracle.DATA_MEAN, oracle.DATA_STD)
+        mu, lv, enc, rec = m(image)
+        loss = m.loss(target, mu, lv, enc, rec, dev, args, deferred=True)[0]
+        opt.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        opt.step()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), grads, m._flat.detach().clone(), m._bnf.detach().clone(), rec.detach().clone()
+
+    a = run(False)
+    b = run(True)
+    assert torch.equal(a[4], b[4]), "reconstruction differs"
+    assert torch.equal(a[0], b[0]), (a[0].item(), b[0].item())
+    bad = [k for k in a[1] if not torch.equal(a[1][k], b[1][k])]
+    assert not bad, f"gradients differ between two runs of the same step: {bad[:8]} ({len(bad)} of {len(a[1])})"
+    assert torch.equal(a[3], b[3]), "BatchNorm running statistics differ"
+    assert torch.equal(a[2], b[2]), "parameters after Adam differ"

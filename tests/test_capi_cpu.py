@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(L.PROTOTYPES) == syms, "ctypes prototypes and header drifted apart"
-    assert lib.mmvae_abi_version() == 1
+    assert lib.mmvae_abi_version() == 3
 
 
 def test_inventory_matches_oracle_spec(pkg, oracle):
