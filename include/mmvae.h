@@ -225,10 +225,13 @@ MMVAE_API int mmvae_stem_bwd(int dtype, const void* g, const void* y0, const voi
 /* ConvTranspose2d backward in one pass over dy (bf16; Cin = Cout = 16, k4 s2 p1, 32x32 -> 64x64; else MMVAE_ERR_UNSUPPORTED):
  * dweight (Cin,Cout,4,4) += , dx [N,H,W,Cin] = d(loss)/dx  (+ x2 (x) w2: x2 [N,H,W,16], w2 f32 (Cin,16,1,1), both nullable).
  * pro_*: as in mmvae_conv2d_wgrad (applied to x).  scratch: (numel(weight) + numel(w2)) * sizeof(dtype) for the packed weights;
- * wscratch: MMVAE_WGRAD_SCRATCH_BYTES. */
+ * wscratch: MMVAE_WGRAD_SCRATCH_BYTES.
+ * dw2 (nullable, needs x2): the weight gradient of the 1x1 convolution whose data gradient x2 (x) w2 is -- x2 is that conv's output
+ * gradient, pro(x) its input -- in the Conv2d layout (16, Cin, 1, 1) (the transpose of w2's (Cin, 16)): dw2 += x2^T (x) pro(x), from the
+ * same pass (decoder DeconvBottleneck: conv1's gradient rides on the upsample branch's pass, reference model.py:60,70-72). */
 MMVAE_API int mmvae_convT_bwd_fused(int dtype, const void* x, const void* dy, const float* weight, float* dweight, void* dx, int N, int H, int W,
                           int Cin, int Cout, int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu,
-                          const void* x2, const float* w2, void* scratch, void* wscratch, void* stream);
+                          const void* x2, const float* w2, float* dw2, void* scratch, void* wscratch, void* stream);
 /* ---- last up-block + tail conv, one output plane (decoder.uplayerN -> decoder.conv2, reference model.py:86-88,193) ----
  * y2, ys: the two branch outputs [N,H,W,16] of `dtype` (BatchNorm not yet applied); (s2,b2), (ss,bs): per-channel f32
  * scale/shift of their BatchNorms; the block output is x = relu(y2*s2+b2 + ys*ss+bs).  weight f32 (1,16,3,3), bias f32 (1).

@@ -57,7 +57,7 @@ PROTOTYPES = {
     "mmvae_comm_destroy": (c_int, [P]),
     "mmvae_net_set_sync_bn_comm": (c_int, [P, P]),
     "mmvae_net_set_sync_bn_comm2": (c_int, [P, P, P]),
-    "mmvae_convT_bwd_fused": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P]),
+    "mmvae_convT_bwd_fused": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
     "mmvae_batchnorm_fwd": (c_int, [c_int, P, c_int64, c_int, P, P, P, P, P, c_float, c_float, c_int, P, P, P, P, P]),
     "mmvae_batchnorm_bwd": (c_int, [c_int, P, P, P, c_int64, c_int, P, P, P, P, P, P, P, P]),
     "mmvae_stem_fwd": (c_int, [c_int, P, P, P, c_int, c_int, P, P, P]),

@@ -258,8 +258,8 @@ int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, fl
   return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), sc);
 }
 int mmvae_convT_bwd_fused(int dt, const void* x, const void* dy, const float* w, float* dw, void* dx, int N, int H, int W, int Cin, int Cout, int k,
-                          int s, int p, const float* ps, const float* pb, int relu, const void* x2, const float* w2, void* scratch, void* wscratch,
-                          void* st) {
+                          int s, int p, const float* ps, const float* pb, int relu, const void* x2, const float* w2, float* dw2, void* scratch,
+                          void* wscratch, void* st) {
   const ConvGeom g = geom_for(1, Cin, Cout, k, s, p);
   const int Ho = out_size(1, H, k, s, p), Wo = out_size(1, W, k, s, p);
   if (!scratch || !wscratch) { set_error("convT_bwd_fused: scratch buffers required"); return MMVAE_ERR_ARG; }
@@ -273,7 +273,9 @@ int mmvae_convT_bwd_fused(int dt, const void* x, const void* dy, const float* w,
     rc = launch_pack(dt, pa, S(st)); if (rc < 0) return rc;
     w2p = pa.dst;
   }
-  rc = op_run_bwd_fused(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, sc, dx, w2p ? x2 : nullptr, w2p, dw, S(st), static_cast<float*>(wscratch));
+  if (dw2 && !w2p) { set_error("convT_bwd_fused: dw2 needs x2 and w2"); return MMVAE_ERR_ARG; }
+  rc = op_run_bwd_fused(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, sc, dx, w2p ? x2 : nullptr, w2p, dw, S(st), static_cast<float*>(wscratch), 1.f,
+                        nullptr, dw2, 1.f);
   if (rc == 0) { set_error("convT_bwd_fused: not taken"); return MMVAE_ERR_UNSUPPORTED; }
   return rc < 0 ? rc : MMVAE_OK;
 }

@@ -44,9 +44,11 @@ int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws
 // that kernel's (callers then run op_run_down + op_run_wgrad), <0 on error.  bn_part (optional; P prologue'd, no x2): the pass also
 // leaves the BatchNorm-backward partial sums of P's BatchNorm, rows [return value][2][16] -- the layout launch_bn_bwd_reduce writes.
 // Taken: returns the number of rows (> 0).  scratch: kWgradScratchBytes, not shared with a concurrent wgrad.
+// dW2 (optional, with x2): the weight gradient of the 1x1 conv itself, [16][D0] row-major (Conv2d (out, in, 1, 1)) += scale2 * x2^T (x) pro(P):
+// both rows are in LDS for the pass anyway.
 bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl);
 int op_run_bwd_fused(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                      const void* G, int Hl, int Wl, const void* packed_down, void* dP, const void* x2, const void* w2_packed, float* dW,
-                     hipStream_t s, float* scratch, float scale = 1.f, float* bn_part = nullptr);
+                     hipStream_t s, float* scratch, float scale = 1.f, float* bn_part = nullptr, float* dW2 = nullptr, float scale2 = 1.f);
 
 }  // namespace mmvae

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
   constexpr int RG = 256 / LANES;
   __shared__ float4 sSum[256];
   const int ab = a.Ca * a.Cb;
-  const long wsize = (long)a.ntaps * ab;
+  const long wsize = a.part_stride;
   const int l = threadIdx.x % LANES, rg = threadIdx.x / LANES;
   const float* src = a.part + (long)blockIdx.x * (4 * LANES) + l * 4;
   float4 s[4];
@@ -96,10 +96,12 @@ int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s) {
   bool distinct = true;
   for (int t = 0; t < a.ntaps && distinct; ++t)
     for (int u = 0; u < t; ++u) if (a.tap_off[u] == a.tap_off[t]) { distinct = false; break; }
+  if (a.part_stride <= 0) a.part_stride = (long)a.ntaps * a.Ca * a.Cb;
   if (!distinct) {
     for (int t = 1; t < a.ntaps; ++t)
       if (a.tap_off[t] != a.tap_off[0]) { set_error("wgrad_reduce: taps share some destinations but not all"); return MMVAE_ERR_UNSUPPORTED; }
-    a.nparts *= a.ntaps; a.ntaps = 1;
+    if (a.part_stride != (long)a.ntaps * a.Ca * a.Cb) { set_error("wgrad_reduce: shared destinations need densely packed partial images"); return MMVAE_ERR_UNSUPPORTED; }
+    a.nparts *= a.ntaps; a.ntaps = 1; a.part_stride = (long)a.Ca * a.Cb;
   }
   const long wsize = (long)a.ntaps * a.Ca * a.Cb;
   if (wsize % 256) { set_error("wgrad_reduce: %ld elements not a multiple of 256", wsize); return MMVAE_ERR_ARG; }

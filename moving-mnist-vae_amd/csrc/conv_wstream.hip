@@ -32,6 +32,8 @@ struct WStreamArgs {
   const void* wd;            // packed [Ca][KS*KS][Cb] of T (the conv's "down" form)
   void* dx;                  // [N][Hp][WP][Ca] of T
   const void* x2; const void* w2;   // optional second source on the P grid: x2 [N][Hp][WP][16], w2 packed [Ca][16]
+  // (X2) the pass also accumulates the 1x1 conv's own weight gradient, dW2[c2][a] = sum x2[n,h,w,c2] * pro(P[n,h,w,a]) -- both rows are
+  // in LDS anyway -- as one more image of the block's partial: [NT + 1][16][16]
   // BatchNorm-backward partial sums of the BN that produced P (DG + PRO_P): g = dx * (P*scale+shift > 0); rows [block][2][16]: sum g, sum g * P
   float* bn_part;
 };
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
   constexpr int RAWB = ST ? PB : 0;                        // raw copy of the P row (before the prologue) for the BatchNorm sums
   constexpr int WAVE_LDS = NSLOT * ROWB + PB + X2B + RAWB;
   constexpr int NT = KS * KS;
-  constexpr int WSIZE = NT * CA16 * 16 * CB16 * 16;        // floats of a partial image
+  constexpr int WSIZE = (NT + (X2 ? 1 : 0)) * CA16 * 16 * CB16 * 16;   // floats of a partial image (X2: + the 1x1 conv's 16 x 16)
   static_assert(4 * WAVE_LDS >= WSIZE * 4 + 512, "the flush image (+ 128 floats of BatchNorm sums) aliases the rings");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
 #pragma unroll
       for (int cb = 0; cb < CB16; ++cb) acc[k][ca][cb] = (f32x4){0, 0, 0, 0};
 
+  f32x4 acc2 = (f32x4){0, 0, 0, 0};                         // X2: the 1x1 conv's weight gradient [x2 channel][P channel]
   float bsc[4] = {0, 0, 0, 0}, bsh[4] = {0, 0, 0, 0}, bs0[4] = {0, 0, 0, 0}, bs1[4] = {0, 0, 0, 0};
   if constexpr (ST) {
 #pragma unroll
@@ -224,6 +227,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
           }
         }
       }
+      if constexpr (X2) {
+        // x2^T (16 x 32 pixels) times the prologue'd P row (32 pixels x 16): the same fragment form as af, from the x2 row
+        const Vec16 ax = FragOps<bf16_t>::load(x2row, offA[0], offA[1]);
+        acc2 = mma_bf16(ax, af[0], acc2);
+      }
       if constexpr (DG) {
         // D[a][pixel]: lane (r = pixel of the 16-pixel tile, gq) ends with channels a = 4gq .. 4gq+3
         f32x4 dacc[WP / 16];
@@ -288,6 +296,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_stream_kernel(WStreamArgs a) {
               float* p = img + (k * CA16 * 16 + ca * 16 + 4 * gq + j) * (CB16 * 16) + cb * 16 + r;
               *p = (w == 0 ? 0.f : *p) + acc[k][ca][cb][j];
             }
+      if constexpr (X2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float* p = img + (NT * 16 + 4 * gq + j) * 16 + r;
+          *p = (w == 0 ? 0.f : *p) + acc2[j];
+        }
+      }
     }
     __syncthreads();
   }
@@ -335,7 +350,7 @@ static bool wstream_shape(int dt, const WgradArgs& a) {
   for (int t = 0; t < 16; ++t) if (a.tap_off[t] != t) return false;
   return true;
 }
-static int wstream_fill(const WgradArgs& a, WStreamArgs& b) {
+static int wstream_fill(const WgradArgs& a, WStreamArgs& b, bool x2 = false) {
   memset(&b, 0, sizeof(b));
   b.P = a.P; b.G = a.G; b.part = a.scratch;
   b.proP_scale = a.proP_scale; b.proP_shift = a.proP_shift; b.proP_relu = a.proP_relu;
@@ -345,16 +360,23 @@ static int wstream_fill(const WgradArgs& a, WStreamArgs& b) {
   b.nunits = a.N * (a.Hp / b.HS);
   int gx = 512;                                             // two 4-wave blocks per CU
   while (gx > 8 && (long)gx * 4 > b.nunits) gx -= 8;
-  const int wsize = 16 * a.Ca * a.Cb;
+  const int wsize = (16 + (x2 ? 1 : 0)) * a.Ca * a.Cb;
   if ((size_t)gx * wsize * 4 > kWgradScratchBytes) return 0;
   return gx;
 }
-static int wstream_reduce(const WgradArgs& a, int gx, hipStream_t s) {
+// dW2 (optional, X2 passes): the 1x1 conv's weight (16 outputs = x2 channels, 16 inputs = P channels, row-major) receives the 17th image
+static int wstream_reduce(const WgradArgs& a, int gx, hipStream_t s, bool x2 = false, float* dW2 = nullptr, float scale2 = 1.f) {
   WgradReduceArgs u; memset(&u, 0, sizeof(u));
   u.part = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.nparts = gx;
   u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid; u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
+  u.part_stride = (long)(a.ntaps + (x2 ? 1 : 0)) * a.Ca * a.Cb;
   for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
-  return launch_wgrad_reduce(u, s);
+  const int rc = launch_wgrad_reduce(u, s);
+  if (rc < 0 || !x2 || !dW2) return rc;
+  WgradReduceArgs v; memset(&v, 0, sizeof(v));
+  v.part = a.scratch + (long)a.ntaps * a.Ca * a.Cb; v.part_stride = u.part_stride; v.dW = dW2; v.Ca = 16; v.Cb = a.Ca; v.ntaps = 1; v.nparts = gx;
+  v.Ca_valid = 16; v.Cb_valid = a.Ca; v.sA = a.Ca; v.sB = 1; v.scale = scale2;
+  return launch_wgrad_reduce(v, s);
 }
 
 // Returns 1 when the launch was taken (kernel + reduce enqueued), 0 when the shape is not this kernel's, <0 on error.  MMVAE_WSTREAM=0: off
@@ -382,11 +404,12 @@ bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a) {
   static const int enabled = [] { const char* e = getenv("MMVAE_WSTREAM_DG"); return e ? atoi(e) : 1; }();
   return enabled != 0 && wstream_shape(dt, a) && a.Ca == 16 && !a.proG_scale;
 }
-int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s) {
+int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s,
+                           float* dW2, float scale2) {
   if (!dgrad_wgrad_stream_shape(dt, a) || !wd || !dx || ((x2 != nullptr) != (w2 != nullptr))) return 0;
   if (bn_part && (x2 || !a.proP_scale)) { set_error("dgrad_wgrad_stream: BatchNorm sums need the prologue'd P and no second source"); return MMVAE_ERR_ARG; }
   WStreamArgs b;
-  const int gx = wstream_fill(a, b);
+  const int gx = wstream_fill(a, b, x2 != nullptr);
   if (gx <= 0) return 0;
   b.wd = wd; b.dx = dx; b.x2 = x2; b.w2 = w2; b.bn_part = bn_part;
   const bool pp = a.proP_scale != nullptr;
@@ -395,7 +418,7 @@ int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx,
   else if (bn_part) rc = launch_wstream_t<1, true, false, true, false, true>(b, gx, s);
   else rc = pp ? launch_wstream_t<1, true, false, true, false>(b, gx, s) : launch_wstream_t<1, false, false, true, false>(b, gx, s);
   if (rc < 0) return rc;
-  const int rc2 = wstream_reduce(a, gx, s);
+  const int rc2 = wstream_reduce(a, gx, s, x2 != nullptr, dW2, scale2);
   return rc2 < 0 ? rc2 : gx;             // taken: the number of blocks = rows of bn_part
 }
 

@@ -68,7 +68,9 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
 int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s);   // conv_wstream.hip: 1 = taken, 0 = not this kernel's shape, <0 error
 // weight gradient + data gradient (w.r.t. P) of a 16 -> 16 channel k4 s2 layer in one pass over G (conv_wstream.hip)
 bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a);
-int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s);
+// dW2 (optional, with x2): the 1x1 conv's own weight gradient [16][Ca] += scale2 * x2^T (x) pro(P), from the same pass
+int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s,
+                           float* dW2 = nullptr, float scale2 = 1.f);
 
 // ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
 // A tile is up to TP (128, or 64/32 for wgrad on tiny feature maps) q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.
@@ -110,7 +112,8 @@ int wgrad2_taps_per_block(int ta16, int tb16, int ntaps);
 int launch_wgrad2(int dt, const Wgrad2Args& a, int gx, int tiles_ab, int zg, int ta16, int tb16, hipStream_t s);
 size_t gather3_lds_bytes(const GatherArgs& a, int dt, int CT);
 int launch_gather3(int dt, int out_dt, const GatherArgs& a, int gx, hipStream_t s);
-struct WgradReduceArgs { const float* part; float* dW; int Ca, Cb, ntaps, nparts, Ca_valid, Cb_valid, sA, sB; int tap_off[25]; float scale; int exclusive; };
+struct WgradReduceArgs { const float* part; float* dW; int Ca, Cb, ntaps, nparts, Ca_valid, Cb_valid, sA, sB; int tap_off[25]; float scale; int exclusive;
+                         long part_stride; /* floats between two partial images (0: ntaps * Ca * Cb) */ };
 int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s);
 constexpr size_t kWgradScratchBytes = 64u << 20;   // capacity of the partial-image scratch every wgrad caller provides
 // ---- pipelined all-phases patch kernel (conv_patch.hip)

@@ -150,6 +150,15 @@ Net::Net(const NetCfg& c) : cfg(c) {
   bn_out = add_bn("decoder.bn2", c.out_ch);
 }
 
+Net::~Net() {
+  if (side_state_ != 1) return;
+  // work still queued on the side streams belongs to buffers the caller may free next: drain first
+  if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
+  for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : blk_ev_) if (e) (void)hipEventDestroy(e);
+  (void)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ planning
 size_t Net::workspace_bytes(int N) { return plan(N).bytes; }
 
@@ -191,7 +200,7 @@ const Plan& Net::plan(int N) {
   P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
   P.wscratch = take((long)kWgradScratchBytes);
-  P.wscratch2 = take(512L * 16 * 16 * 16 * 4);        // partial images of a fused dgrad+wgrad pass on the caller's stream (512 blocks x [16][16][16] f32)
+  P.wscratch2 = take(512L * 17 * 16 * 16 * 4);        // partial images of a fused dgrad+wgrad pass on the caller's stream (512 blocks x [16 (+1)][16][16] f32)
   P.stem_R = take(1024 * 8);
   P.stem_gram = take(1024L * stem_bwd_part_floats() * 4);
   P.bytes = (size_t)cur;
@@ -254,23 +263,26 @@ hipStream_t Net::wgrad_stream(hipStream_t s) {
     side_state_ = (e && e[0] == '0') ? -1 : 1;
     if (side_state_ == 1) {
       bool ok = hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) == hipSuccess;
-      for (int i = 0; i < 64 && ok; ++i) ok = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < kForkEvents && ok; ++i) ok = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
       for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&blk_ev_[i], hipEventDisableTiming) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); side_state_ = -1; }
     }
   }
   return side_state_ == 1 ? side_ : s;
 }
+// kForkEvents > 2 x (forks + joins of one backward pass): no event is re-recorded while a wait on it may be pending
 int Net::side_fork(hipStream_t s) {
   if (wgrad_stream(s) == s) return MMVAE_OK;
-  hipEvent_t e = ev_[evi_++ & 63];     // 64 > forks + joins of one backward pass: no event is re-recorded while a wait on it may be pending
-  if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(side_, e, 0) != hipSuccess) { set_error("side stream fork failed"); return MMVAE_ERR_HIP; }
+  hipEvent_t e = ev_[evi_++ % kForkEvents];
+  bool ok = hipEventRecord(e, s) == hipSuccess && hipStreamWaitEvent(side_, e, 0) == hipSuccess;
+  if (!ok) { set_error("side stream fork failed"); return MMVAE_ERR_HIP; }
   return MMVAE_OK;
 }
 int Net::side_join(hipStream_t s) {
   if (wgrad_stream(s) == s) return MMVAE_OK;
-  hipEvent_t e = ev_[evi_++ & 63];     // 64 > forks + joins of one backward pass: no event is re-recorded while a wait on it may be pending
-  if (hipEventRecord(e, side_) != hipSuccess || hipStreamWaitEvent(s, e, 0) != hipSuccess) { set_error("side stream join failed"); return MMVAE_ERR_HIP; }
+  hipEvent_t e = ev_[evi_++ % kForkEvents];
+  bool ok = hipEventRecord(e, side_) == hipSuccess && hipStreamWaitEvent(s, e, 0) == hipSuccess;
+  if (!ok) { set_error("side stream join failed"); return MMVAE_ERR_HIP; }
   return MMVAE_OK;
 }
 
@@ -288,17 +300,21 @@ static bool stem_im2col_path() {
 
 int Net::side_mark(int slot) {
   if (side_state_ != 1) return MMVAE_OK;
-  if (hipEventRecord(blk_ev_[slot & 15], side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
+  bool ok = hipEventRecord(blk_ev_[slot & 15], side_) == hipSuccess;
+  if (!ok) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
   return MMVAE_OK;
 }
 int Net::side_wait_mark(int slot, hipStream_t s) {
   if (side_state_ != 1) return MMVAE_OK;
-  if (hipStreamWaitEvent(s, blk_ev_[slot & 15], 0) != hipSuccess) { set_error("side stream wait failed"); return MMVAE_ERR_HIP; }
+  bool ok = hipStreamWaitEvent(s, blk_ev_[slot & 15], 0) == hipSuccess;
+  if (!ok) { set_error("side stream wait failed"); return MMVAE_ERR_HIP; }
   return MMVAE_OK;
 }
 
 int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b,
                    const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, float* grads, hipStream_t s) {
+  // (measured in round 3: a SECOND side stream with its own scratch, the weight gradients alternating between the two, is slower --
+  // 7.74 vs 7.63 ms per step: the phases where the side stream lags are bandwidth-bound, two wgrad kernels at once only thrash)
   return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_, w.wscale);
 }
 
@@ -979,15 +995,16 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                B.C, s));
     // conv1 (1x1): wgrad(P = dy1, G = xin); upsample (ConvT): wgrad(P = xin, G = dys)
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c1, N, base + P.dy1[ds], B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    // (with the fused shortcut pass below the 1x1 conv's weight gradient comes out of that pass: dy1 and the block input are its rows)
+    if (!fuse_cs) MM_TRY(run_wgrad(B.c1, N, base + P.dy1[ds], B.Hin, B.Win, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(side_mark(i));
     if (B.identity)     // d_xin already holds the shortcut's share: the 1x1 conv's data gradient is added to it
       MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
-    else if (fuse_cs) {  // shortcut ConvT: weight gradient + data gradient + the 1x1 conv's share (dy1 (x) w1), one pass over dys
+    else if (fuse_cs) {  // shortcut ConvT: weight gradient + data gradient + the 1x1 conv's share (dy1 (x) w1) and ITS weight gradient, one pass over dys
       const int rcf = op_run_bwd_fused(dt(), geom(B.cs), N, xin, B.Hin, B.Win, xs, xb, 1, base + P.dys[ds], B.Hout, B.Wout,
                                        base + plan_.packed + B.cs.packD * (long)esz(), base + P.g[cur ^ 1], base + P.dy1[ds],
                                        base + plan_.packed + B.c1.packU * (long)esz(), grads + B.cs.off, s,
-                                       reinterpret_cast<float*>(base + P.wscratch2), B.cs.wscale);
+                                       reinterpret_cast<float*>(base + P.wscratch2), B.cs.wscale, nullptr, grads + B.c1.off, B.c1.wscale);
       if (rcf <= 0) { if (rcf == 0) set_error("decoder_bwd: fused backward of %s not taken", "upsample"); return rcf < 0 ? rcf : MMVAE_ERR_UNSUPPORTED; }
     } else              // one kernel: the 1x1 conv's data gradient (dy1, already on this block's input grid) is a second source of the shortcut's
       MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s,

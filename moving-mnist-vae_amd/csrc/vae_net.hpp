@@ -47,7 +47,7 @@ struct Plan {
                                                           // stream may still read the shared sets for the decoder when they run
   long g[2], dy1[2], dy2[2], dys[2], da1, dh;            // backward temporaries (dy*: two sets, alternating per block, so the
                                                          // weight gradients on the side stream may lag one block behind)
-  long wscratch;                                         // [tap][a][b] reduction image of the largest weight gradient
+  long wscratch;                                         // partial-image scratch of the weight gradients (serialised on the side stream)
   long wscratch2;                                        // partial images of the fused dgrad+wgrad passes (caller's stream)
   long stem_R, stem_gram;
   long cvec;                                             // constants: 256 ones, 256 zeros (identity shortcuts as a unit BatchNorm)
@@ -60,6 +60,9 @@ constexpr long kPartialFloats = 4096L * 3 * 256;   // floats of one reduction-pa
 class Net {
  public:
   explicit Net(const NetCfg& c);
+  ~Net();                            // destroys the side streams / events the net created (the caller's buffers are the caller's)
+  Net(const Net&) = delete;
+  Net& operator=(const Net&) = delete;
   NetCfg cfg;
   std::vector<Entry> entries;
   long n_params = 0, n_bnbuf = 0; int n_nbt = 0;
@@ -94,7 +97,8 @@ class Net {
   float* wscratch_ = nullptr;
   // weight gradients run on a side stream, concurrently with the dgrad / BatchNorm-backward chain of the same block
   // (the deep-layer kernels are latency-bound and leave most CUs idle); MMVAE_SIDE_STREAM=0 disables it
-  hipStream_t side_ = nullptr; hipEvent_t ev_[64] = {}; int evi_ = 0; int side_state_ = 0;   // 0 unknown, 1 on, -1 off
+  static constexpr int kForkEvents = 192;
+  hipStream_t side_ = nullptr; hipEvent_t ev_[kForkEvents] = {}; int evi_ = 0; int side_state_ = 0;   // 0 unknown, 1 on, -1 off
   hipStream_t wgrad_stream(hipStream_t s);      // stream the weight gradients are enqueued on
   int side_fork(hipStream_t s);                 // side stream waits for everything enqueued on s so far
   int side_join(hipStream_t s);                 // s waits for everything enqueued on the side stream so far

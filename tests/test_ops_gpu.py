@@ -179,6 +179,7 @@ def test_convT_backward_in_one_pass(N, prologue, second):
         x2 = _round(torch.randn(N, 16, H, H, generator=g), "bf16")
         w2 = torch.randn(C, 16, generator=g) / 4.0
         dx_ref = dx_ref + torch.einsum("nkhw,ak->nahw", x2, _round(w2, "bf16"))
+        dw2_ref = torch.einsum("nkhw,nahw->ka", x2, xin)          # the 1x1 conv's own weight gradient, (out = 16, in = C)
     st = torch.cuda.current_stream().cuda_stream
     xd, dyd = _to_dev(x, "bf16"), _to_dev(dy, "bf16")
     wd = w.cuda()
@@ -189,14 +190,18 @@ def test_convT_backward_in_one_pass(N, prologue, second):
     psd = ps.cuda() if prologue else None
     pbd = pb.cuda() if prologue else None
     scratch = torch.empty(16384, dtype=torch.uint8, device="cuda")
+    dw2d = torch.zeros(16, C, device="cuda") if second else None
     L.check(lib.mmvae_convT_bwd_fused(1, L.ptr(xd), L.ptr(dyd), L.ptr(wd), L.ptr(dwd), L.ptr(dxd), N, H, H, C, C, 4, 2, 1, L.ptr(psd), L.ptr(pbd), 1,
-                                      L.ptr(x2d), L.ptr(w2d), L.ptr(scratch), L.ptr(_wgrad_scratch()), st), "convT_bwd_fused")
+                                      L.ptr(x2d), L.ptr(w2d), L.ptr(dw2d), L.ptr(scratch), L.ptr(_wgrad_scratch()), st), "convT_bwd_fused")
     torch.cuda.synchronize()
+    if second:
+        e_dw2 = ((dw2d.cpu() - dw2_ref).abs().max() / dw2_ref.abs().max()).item()
+        assert e_dw2 == e_dw2 and e_dw2 < 1.5e-2, e_dw2
     e_dx = ((_from_dev(dxd) - dx_ref).abs().max() / dx_ref.abs().max()).item()
     e_dw = ((dwd.cpu() - wr.grad).abs().max() / wr.grad.abs().max()).item()
     assert e_dx == e_dx and e_dx < 1e-2 and e_dw < 1.5e-2, (e_dx, e_dw)
     # shapes the kernel does not take are refused, not mis-computed
-    rc = lib.mmvae_convT_bwd_fused(1, L.ptr(xd), L.ptr(dyd), L.ptr(wd), L.ptr(dwd), L.ptr(dxd), N, 16, 16, C, C, 4, 2, 1, None, None, 0, None, None,
+    rc = lib.mmvae_convT_bwd_fused(1, L.ptr(xd), L.ptr(dyd), L.ptr(wd), L.ptr(dwd), L.ptr(dxd), N, 16, 16, C, C, 4, 2, 1, None, None, 0, None, None, None,
                                    L.ptr(scratch), L.ptr(_wgrad_scratch()), st)
     assert rc < 0
 

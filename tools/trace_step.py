@@ -19,6 +19,7 @@ def main(path, marker="adam"):
     lo, hi = ends[-2] + 1, ends[-1] + 1
     step = rows[lo:hi]
     t0 = int(step[0]["Start_Timestamp"])
+    main_q = step[-1]["Queue_Id"]              # the Adam kernel runs on the caller's stream
     tot = defaultdict(lambda: [0, 0.0])
     busy = 0.0
     for i, r in enumerate(step):
@@ -28,7 +29,8 @@ def main(path, marker="adam"):
         tot[k][0] += 1
         tot[k][1] += d
         grid = "x".join(str(int(r[f"Grid_Size_{a}"]) // max(1, int(r[f"Workgroup_Size_{a}"]))) for a in "XYZ")
-        print(f"{i:4d} {(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {d:8.1f}us  grid {grid:14s} lds {r.get('LDS_Block_Size', '?'):>6s}  {k}")
+        q = "M" if r["Queue_Id"] == main_q else "s"
+        print(f"{i:4d} {q} {(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} {d:8.1f}us  grid {grid:14s} lds {r.get('LDS_Block_Size', '?'):>6s}  {k}")
     wall = (int(step[-1]["End_Timestamp"]) - t0) / 1e3
     print(f"\nstep: {len(step)} launches, busy {busy / 1e3:.3f} ms, span {wall / 1e3:.3f} ms")
     for k, (n, d) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:40]:
