@@ -222,7 +222,8 @@ MMVAE_API int mmvae_stem_fwd(int dtype, const void* x, const float* weight, void
 MMVAE_API int mmvae_stem_bwd(int dtype, const void* g, const void* y0, const void* x, const float* weight, const float* gamma,
                    const float* bn_scale, const float* bn_shift, const float* save_mean, const float* save_istd, float* dweight,
                    float* dgamma, float* dbeta, int N, int S, void* scratch, void* stream);
-/* ConvTranspose2d backward in one pass over dy (bf16; Cin = Cout = 16, k4 s2 p1, 32x32 -> 64x64; else MMVAE_ERR_UNSUPPORTED):
+/* ConvTranspose2d backward in one pass over dy (bf16; Cin = 16 or 32, Cout = 16, k4 s2 p1, 32x32 -> 64x64 or 16x16 -> 32x32; else
+ * MMVAE_ERR_UNSUPPORTED):
  * dweight (Cin,Cout,4,4) += , dx [N,H,W,Cin] = d(loss)/dx  (+ x2 (x) w2: x2 [N,H,W,16], w2 f32 (Cin,16,1,1), both nullable).
  * pro_*: as in mmvae_conv2d_wgrad (applied to x).  scratch: (numel(weight) + numel(w2)) * sizeof(dtype) for the packed weights;
  * wscratch: MMVAE_WGRAD_SCRATCH_BYTES.

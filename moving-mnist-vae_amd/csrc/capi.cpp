@@ -263,7 +263,7 @@ int mmvae_convT_bwd_fused(int dt, const void* x, const void* dy, const float* w,
   const ConvGeom g = geom_for(1, Cin, Cout, k, s, p);
   const int Ho = out_size(1, H, k, s, p), Wo = out_size(1, W, k, s, p);
   if (!scratch || !wscratch) { set_error("convT_bwd_fused: scratch buffers required"); return MMVAE_ERR_ARG; }
-  if (!op_bwd_fusable(dt, g, N, H, W, Ho, Wo)) { set_error("convT_bwd_fused: shape not supported (bf16, 16 -> 16 channels, k4 s2 p1, 32x32 -> 64x64)"); return MMVAE_ERR_UNSUPPORTED; }
+  if (!op_bwd_fusable(dt, g, N, H, W, Ho, Wo)) { set_error("convT_bwd_fused: shape not supported (bf16, 16 / 32 -> 16 channels, k4 s2 p1, 32x32 -> 64x64 or 16x16 -> 32x32)"); return MMVAE_ERR_UNSUPPORTED; }
   char* sc = static_cast<char*>(scratch);
   int rc = op_pack_down(dt, g, w, sc, S(st)); if (rc < 0) return rc;
   const void* w2p = nullptr;

@@ -200,7 +200,7 @@ const Plan& Net::plan(int N) {
   P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
   P.wscratch = take((long)kWgradScratchBytes);
-  P.wscratch2 = take(512L * 17 * 16 * 16 * 4);        // partial images of a fused dgrad+wgrad pass on the caller's stream (512 blocks x [16 (+1)][16][16] f32)
+  P.wscratch2 = take(512L * (16 * 32 * 16 + 16 * 32) * 4);   // partial images of a fused dgrad+wgrad pass on the caller's stream (512 blocks x ([16][32][16] + [16][32]) f32)
   P.stem_R = take(1024 * 8);
   P.stem_gram = take(1024L * stem_bwd_part_floats() * 4);
   P.bytes = (size_t)cur;
@@ -968,8 +968,9 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       MM_TRY(run_up(B.c2, base, N, base + P.dy2[ds], B.Hout, B.Wout, base + P.da1, B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s));
     } else {
       // conv2 (ConvT k4 s2): wgrad(P = a1 small side with BN+ReLU prologue, G = dy2 large side); dgrad = strided conv -> d_a1
-      // Where the shape allows (uplayer5: 16 -> 16 channels, 32x32 -> 64x64, bf16) dgrad and wgrad of a ConvT are ONE pass over its dy
-      // tensor on the caller's stream (wgrad_stream_kernel with DG): dy2 / dys (671 MB each at N = 5120) are read once instead of twice.
+      // Where the shape allows (uplayer4 / uplayer5: 16 output channels, 16x16 -> 32x32 or 32x32 -> 64x64, bf16) dgrad and wgrad of a ConvT
+      // are ONE pass over its dy tensor on the caller's stream (wgrad_stream_kernel with DG): dy2 / dys (671 MB each at N = 5120 in
+      // uplayer5) are read once instead of twice.
       fuse_c2 = !B.c2.fp8 && op_bwd_fusable(dt(), geom(B.c2), N, B.Hin, B.Win, B.Hout, B.Wout);
       fuse_cs = !B.cs.fp8 && op_bwd_fusable(dt(), geom(B.cs), N, B.Hin, B.Win, B.Hout, B.Wout) && B.C == 16;
       float* wsc2 = reinterpret_cast<float*>(base + P.wscratch2);

@@ -152,15 +152,16 @@ def test_conv_ops_with_fused_bn_relu_prologue(cfg, dt):
 @pytest.mark.parametrize("N", [1, 5, 37])
 @pytest.mark.parametrize("prologue", [False, True])
 @pytest.mark.parametrize("second", [False, True])
-def test_convT_backward_in_one_pass(N, prologue, second):
+@pytest.mark.parametrize("C,H", [(16, 32), (16, 16), (32, 16), (32, 32)])
+def test_convT_backward_in_one_pass(N, prologue, second, C, H):
     """mmvae_convT_bwd_fused: weight gradient and data gradient of a ConvTranspose2d(16 -> 16, k4 s2 p1) on 32x32 -> 64x64 maps from ONE
     pass over dy (wgrad_stream_kernel with DG), optionally with the 1x1 shortcut's share x2 (x) w2 added to dx -- against PyTorch fp32."""
     L = _lib()
     lib = L.lib()
     g = torch.Generator().manual_seed(100 + N)
-    C, H = 16, 32
+    CO = 16
     x = _round(torch.randn(N, C, H, H, generator=g), "bf16")
-    w = torch.randn(C, C, 4, 4, generator=g) / 8.0
+    w = torch.randn(C, CO, 4, 4, generator=g) / 8.0
     wq = _round(w, "bf16")
     ps = pb = None
     xin = x
@@ -183,15 +184,15 @@ def test_convT_backward_in_one_pass(N, prologue, second):
     st = torch.cuda.current_stream().cuda_stream
     xd, dyd = _to_dev(x, "bf16"), _to_dev(dy, "bf16")
     wd = w.cuda()
-    dwd = torch.zeros(C, C, 4, 4, device="cuda")
+    dwd = torch.zeros(C, CO, 4, 4, device="cuda")
     dxd = torch.full((N, H, H, C), float("nan"), device="cuda", dtype=torch.bfloat16)
     x2d = _to_dev(x2, "bf16") if second else None
     w2d = w2.cuda() if second else None
     psd = ps.cuda() if prologue else None
     pbd = pb.cuda() if prologue else None
-    scratch = torch.empty(16384, dtype=torch.uint8, device="cuda")
+    scratch = torch.empty(65536, dtype=torch.uint8, device="cuda")
     dw2d = torch.zeros(16, C, device="cuda") if second else None
-    L.check(lib.mmvae_convT_bwd_fused(1, L.ptr(xd), L.ptr(dyd), L.ptr(wd), L.ptr(dwd), L.ptr(dxd), N, H, H, C, C, 4, 2, 1, L.ptr(psd), L.ptr(pbd), 1,
+    L.check(lib.mmvae_convT_bwd_fused(1, L.ptr(xd), L.ptr(dyd), L.ptr(wd), L.ptr(dwd), L.ptr(dxd), N, H, H, C, CO, 4, 2, 1, L.ptr(psd), L.ptr(pbd), 1,
                                       L.ptr(x2d), L.ptr(w2d), L.ptr(dw2d), L.ptr(scratch), L.ptr(_wgrad_scratch()), st), "convT_bwd_fused")
     torch.cuda.synchronize()
     if second:
@@ -201,7 +202,7 @@ def test_convT_backward_in_one_pass(N, prologue, second):
     e_dw = ((dwd.cpu() - wr.grad).abs().max() / wr.grad.abs().max()).item()
     assert e_dx == e_dx and e_dx < 1e-2 and e_dw < 1.5e-2, (e_dx, e_dw)
     # shapes the kernel does not take are refused, not mis-computed
-    rc = lib.mmvae_convT_bwd_fused(1, L.ptr(xd), L.ptr(dyd), L.ptr(wd), L.ptr(dwd), L.ptr(dxd), N, 16, 16, C, C, 4, 2, 1, None, None, 0, None, None, None,
+    rc = lib.mmvae_convT_bwd_fused(1, L.ptr(xd), L.ptr(dyd), L.ptr(wd), L.ptr(dwd), L.ptr(dxd), N, 8, 8, C, CO, 4, 2, 1, None, None, 0, None, None, None,
                                    L.ptr(scratch), L.ptr(_wgrad_scratch()), st)
     assert rc < 0
 
