@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
+# (MMVAE_LIB_PATH: developer A/B runs of two builds on one box; the product always loads the in-tree library)
+LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")
 _lib = None
 
 P = c_void_p

@@ -156,6 +156,7 @@ Net::~Net() {
   if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); }
   for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : blk_ev_) if (e) (void)hipEventDestroy(e);
+  if (gram_ev_) (void)hipEventDestroy(gram_ev_);
   (void)hipGetLastError();
 }
 
@@ -265,6 +266,7 @@ hipStream_t Net::wgrad_stream(hipStream_t s) {
       bool ok = hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) == hipSuccess;
       for (int i = 0; i < kForkEvents && ok; ++i) ok = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
       for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&blk_ev_[i], hipEventDisableTiming) == hipSuccess;
+      if (ok) ok = hipEventCreateWithFlags(&gram_ev_, hipEventDisableTiming) == hipSuccess;
       if (!ok) { (void)hipGetLastError(); side_state_ = -1; }
     }
   }
@@ -620,9 +622,12 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
     // the stem's im2col depends on the input image only: early, off the tail of the critical path
     // the stem's input-only work (patch gram matrix / im2col) early, off the tail of the critical path
-    if (stem_bwd_fused())
+    if (stem_bwd_fused()) {
       MM_TRY(launch_stem_gram(dt(), base + P.x_t, reinterpret_cast<float*>(base + P.stem_gram), 1024L * stem_bwd_part_floats(),
                               reinterpret_cast<double*>(base + P.stem_R), N, cfg.S, H1, W1, wgrad_stream(s)));
+      // the stem's finalize at the very end waits for THIS, not for the whole side stream (whose last weight gradients may still run)
+      if (side_state_ == 1 && hipEventRecord(gram_ev_, side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
+    }
     if (!stem_bwd_fused() && stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
@@ -705,11 +710,11 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
       MM_TRY(sync_rows(base, part, np, 64, s, &row, stem_bwd_part_floats()));
       gsum = row; cnt *= ar_world_;
     }
-    MM_TRY(side_join(s));            // the gram matrix (side stream) and every weight gradient of this pass
+    if (side_state_ == 1 && hipStreamWaitEvent(s, gram_ev_, 0) != hipSuccess) { set_error("side stream wait failed"); return MMVAE_ERR_HIP; }
     MM_TRY(launch_stem_bwd_finalize(part, np, reinterpret_cast<const double*>(base + P.stem_R), params + stem.off, gsum, cnt,
                                     params + bn0.g_off, bnf(bn0, base, 0), bnf(bn0, base, 1), grads + bn0.g_off, grads + bn0.b_off,
                                     grads + stem.off, s));
-    return MMVAE_OK;
+    return side_join(s);             // every weight gradient of this pass
   }
   // ---- stem: bn0 + relu backward, then the 5x5 weight gradient
   MM_TRY(side_wait_mark(1, s));    // the stem uses dy set 1 (block index -1): block 1's weight gradients read it last

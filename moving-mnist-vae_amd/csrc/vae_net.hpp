@@ -102,6 +102,7 @@ class Net {
   hipStream_t wgrad_stream(hipStream_t s);      // stream the weight gradients are enqueued on
   int side_fork(hipStream_t s);                 // side stream waits for everything enqueued on s so far
   int side_join(hipStream_t s);                 // s waits for everything enqueued on the side stream so far
+  hipEvent_t gram_ev_ = nullptr;                 // the stem's patch gram matrix is ready (side stream)
   hipEvent_t blk_ev_[16] = {};                   // side-stream progress marks, one per block of a backward pass
   int side_mark(int slot);                      // record mark `slot` on the side stream
   int side_wait_mark(int slot, hipStream_t s);  // s waits for mark `slot`
