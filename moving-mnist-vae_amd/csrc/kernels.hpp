@@ -72,6 +72,27 @@ bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a);
 int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s,
                            float* dW2 = nullptr, float scale2 = 1.f);
 
+// ---- last up-block backward in one pass (conv_joinbwd.hip): the join's BatchNorm backward (incoming gradient recomputed from the
+// one-plane reconstruction gradient), both ConvTranspose2d weight gradients and data gradients, bn1's backward sums -- dy2 / dys are
+// never stored.  bf16, 16 channels, 32x32 -> 64x64, one output plane.  Coefficients: ms* / mb* forward scale / shift, A / B / C the
+// BatchNorm-backward coefficients of the two branch BatchNorms (bn_bwd_finalize).
+struct JoinBwdLaunch {
+  const float* d_raw; const float* w_tail; const void* y2; const void* ys;
+  const float* ms2; const float* mb2; const float* mss; const float* mbs;
+  const float* A2; const float* B2; const float* C2; const float* As; const float* Bs; const float* Cs;
+  const void* y1; const float* p1s; const float* p1b; const void* wd2; void* da1; float* part2; float* bn_part;   // main path (conv2)
+  const void* xin; const float* pxs; const float* pxb; const void* wds; void* gin; float* parts;                  // shortcut (upsample)
+  int N;
+};
+bool join_bwd_stream_ok(int dt, int OC, int C, int Hp, int Hg);
+int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s);    // returns blocks = partial images per conv = rows of bn_part
+// ... and the block's 1x1 conv afterwards: dy1 from d_a1 (bn1 backward), g_in += dy1 (x) W1 in place, dW1 partial images [blocks][16][16]
+struct Conv1BwdLaunch {
+  const void* da1; const void* y1; const float* ms; const float* mb; const float* A; const float* B; const float* C;
+  const void* xin; const float* pxs; const float* pxb; const void* w1u; void* gin; float* part; long nrows;
+};
+int launch_conv1_bwd_stream(const Conv1BwdLaunch& L, hipStream_t s);  // returns blocks
+
 // ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
 // A tile is up to TP (128, or 64/32 for wgrad on tiny feature maps) q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.
 // Its input patch per segment is PR x PW pixels starting at input (hq0*SI + oh, ow).

@@ -953,6 +953,50 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(np);
     if (B.identity) MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
     else MM_TRY(bn_backward_coefs_join(B.b2, B.bs, params, grads, base, np, (double)npo, s));
+    // The last up-block in one pass (conv_joinbwd.hip): dy2 / dys are produced row by row inside the kernel that consumes them -- both
+    // ConvTranspose2d weight gradients, both data gradients, bn1's backward sums -- and never stored; conv1 (1x1) follows once bn1's
+    // sums are final.
+    if (from_tail && !B.identity && !B.c2.fp8 && !B.cs.fp8 && !B.c1.fp8 && B.Cin == 16 && join_bwd_stream_ok(dt(), cfg.out_ch, B.C, B.Hin, B.Hout)) {
+      float* ws2 = reinterpret_cast<float*>(base + P.wscratch2);
+      JoinBwdLaunch L;
+      L.d_raw = d_raw; L.w_tail = params + tail.off; L.y2 = base + B.y2; L.ys = base + B.ys;
+      L.ms2 = bnf(B.b2, base, 2); L.mb2 = bnf(B.b2, base, 3); L.mss = bnf(B.bs, base, 2); L.mbs = bnf(B.bs, base, 3);
+      L.A2 = bnf(B.b2, base, 4); L.B2 = bnf(B.b2, base, 5); L.C2 = bnf(B.b2, base, 6);
+      L.As = bnf(B.bs, base, 4); L.Bs = bnf(B.bs, base, 5); L.Cs = bnf(B.bs, base, 6);
+      L.y1 = base + B.y1; L.p1s = bnf(B.b1, base, 2); L.p1b = bnf(B.b1, base, 3);
+      L.wd2 = base + plan_.packed + B.c2.packD * (long)esz(); L.da1 = base + P.da1; L.part2 = ws2; L.bn_part = part;
+      L.xin = xin; L.pxs = xs; L.pxb = xb; L.wds = base + plan_.packed + B.cs.packD * (long)esz(); L.gin = base + P.g[cur ^ 1];
+      L.parts = ws2 + 512L * 4096;                         // (at most 512 blocks, one [16][16][16] partial image per conv each)
+      L.N = N;
+      const int nb = launch_join_bwd_stream(L, s);
+      MM_TRY(nb);
+      auto reduce16 = [&](const float* parts, int nparts, const ConvW& w, int ntaps) {
+        WgradReduceArgs u; std::memset(&u, 0, sizeof(u));
+        u.part = parts; u.dW = grads + w.off; u.Ca = w.D0; u.Cb = w.D1; u.ntaps = ntaps; u.nparts = nparts;
+        u.Ca_valid = w.D0; u.Cb_valid = w.D1; u.sA = w.D1 * ntaps; u.sB = ntaps; u.scale = w.wscale;
+        for (int t = 0; t < ntaps; ++t) u.tap_off[t] = t;
+        return launch_wgrad_reduce(u, s);
+      };
+      MM_TRY(reduce16(L.part2, nb, B.c2, 16));
+      MM_TRY(reduce16(L.parts, nb, B.cs, 16));
+      MM_TRY(bn_backward_coefs(B.b1, params, grads, base, nb, 1, 0, (double)npi, s));
+      Conv1BwdLaunch C1;
+      C1.da1 = base + P.da1; C1.y1 = base + B.y1; C1.ms = bnf(B.b1, base, 2); C1.mb = bnf(B.b1, base, 3);
+      C1.A = bnf(B.b1, base, 4); C1.B = bnf(B.b1, base, 5); C1.C = bnf(B.b1, base, 6);
+      C1.xin = xin; C1.pxs = xs; C1.pxb = xb; C1.w1u = base + plan_.packed + B.c1.packU * (long)esz();
+      C1.gin = base + P.g[cur ^ 1]; C1.part = ws2; C1.nrows = (long)N * B.Hin;
+      const int nb1 = launch_conv1_bwd_stream(C1, s);
+      MM_TRY(nb1);
+      {   // conv1: Conv2d weight (out = 16, in = Cin): partial images [out][in]
+        WgradReduceArgs u; std::memset(&u, 0, sizeof(u));
+        u.part = ws2; u.dW = grads + B.c1.off; u.Ca = B.c1.D0; u.Cb = B.c1.D1; u.ntaps = 1; u.nparts = nb1;
+        u.Ca_valid = B.c1.D0; u.Cb_valid = B.c1.D1; u.sA = B.c1.D1; u.sB = 1; u.scale = B.c1.wscale;
+        MM_TRY(launch_wgrad_reduce(u, s));
+      }
+      MM_TRY(side_mark(i));
+      cur ^= 1;
+      continue;
+    }
     if (from_tail)
       MM_TRY(launch_tail_join_bwd_apply(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
                                         bnf(B.bs, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5), bnf(B.b2, base, 6), base + P.dy2[ds],
