@@ -260,6 +260,24 @@ MMVAE_API int mmvae_tail_join_bwd_apply(int dtype, const float* d_raw, const flo
                               const float* b2, const void* ys, const float* ss, const float* bs, const float* A2, const float* B2,
                               const float* C2, const float* As, const float* Bs, const float* Cs, void* dy2, void* dys, int N, int H, int W,
                               void* stream);
+/* ---- the last up-block's backward in ONE pass (conv_joinbwd.hip; bf16, 16 channels, 32x32 -> 64x64, one output plane) ----
+ * DeconvBottleneck (reference model.py:70-85) in front of the tail conv (:193): with the join's BatchNorm-backward coefficients at hand
+ * (mmvae_tail_join_bwd_reduce + finalize), the kernel produces dy2 / dys row by row in LDS and consumes them in place:
+ *   dw_conv2 (16,16,4,4) += a1^T (x) dy2,  d_a1 = conv2's data gradient [N,32,32,16],  bn1_sums[2][16] = (sum g, sum g*y1), g = d_a1 [bn1(y1) > 0]
+ *   dw_up    (16,16,4,4) += pro(xin)^T (x) dys,  g_in = the upsample branch's data gradient [N,32,32,16]   (conv1's share: mmvae_conv1x1_bwd_fused)
+ * y1: conv2's input before bn1 (s1, b1 = bn1's scale / shift, ReLU); xin: the block input (sx, bx: optional BatchNorm+ReLU in front, nullable).
+ * Nothing of size dy2 / dys is written.  scratch: MMVAE_WGRAD_SCRATCH_BYTES (packed weights, partial images). */
+MMVAE_API int mmvae_upblock_bwd_fused(const float* d_raw, const float* tail_weight, const void* y2, const float* s2, const float* b2,
+                            const void* ys, const float* ss, const float* bs, const float* A2, const float* B2, const float* C2,
+                            const float* As, const float* Bs, const float* Cs, const void* y1, const float* s1, const float* b1,
+                            const float* w_conv2, float* dw_conv2, void* d_a1, float* bn1_sums, const void* xin, const float* sx,
+                            const float* bx, const float* w_up, float* dw_up, void* g_in, int N, void* scratch, void* stream);
+/* conv1 (1x1, 16 -> 16) of the same block, once bn1's sums are final (A1, B1, C1 = its backward coefficients):
+ *   dy1 = A1 (d_a1 [bn1(y1) > 0]) + B1 y1 + C1;  g_in += dy1 (x) W1 (in place);  dw_conv1 (16,16,1,1) += dy1^T (x) pro(xin).
+ * rows = N * H rows of 32 pixels.  scratch: MMVAE_WGRAD_SCRATCH_BYTES. */
+MMVAE_API int mmvae_conv1x1_bwd_fused(const void* d_a1, const void* y1, const float* s1, const float* b1, const float* A1, const float* B1,
+                            const float* C1, const void* xin, const float* sx, const float* bx, const float* w_conv1, float* dw_conv1,
+                            void* g_in, int64_t rows, void* scratch, void* stream);
 /* f32 <-> dtype element conversion (n elements) */
 MMVAE_API int mmvae_convert(int dtype_in, int dtype_out, const void* in, void* out, int64_t n, void* stream);
 

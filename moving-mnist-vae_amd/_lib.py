@@ -67,6 +67,8 @@ PROTOTYPES = {
     "mmvae_tail_join_fwd_stream": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_tail_join_bwd_reduce": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_tail_join_bwd_apply": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "mmvae_upblock_bwd_fused": (c_int, [P] * 27 + [c_int, P, P]),
+    "mmvae_conv1x1_bwd_fused": (c_int, [P] * 13 + [c_int64, P, P]),
     "mmvae_convert": (c_int, [c_int, c_int, P, P, c_int64, P]),
 }
 

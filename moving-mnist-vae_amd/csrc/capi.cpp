@@ -364,6 +364,54 @@ int mmvae_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int oc
                               const float* As, const float* Bs, const float* Cs, void* dy2, void* dys, int N, int H, int W, void* st) {
   return launch_tail_join_bwd_apply(dt, d_raw, w, oc, N, H, W, s2, b2, ss, bs, y2, A2, B2, C2, dy2, ys, As, Bs, Cs, dys, S(st));
 }
+int mmvae_upblock_bwd_fused(const float* d_raw, const float* tw, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss,
+                            const float* bs, const float* A2, const float* B2, const float* C2, const float* As, const float* Bs, const float* Cs,
+                            const void* y1, const float* s1, const float* b1, const float* w2, float* dw2, void* da1, float* bn1_sums,
+                            const void* xin, const float* sx, const float* bx, const float* wu, float* dwu, void* gin, int N, void* scratch, void* st) {
+  if (!scratch || !d_raw || !tw || !y2 || !ys || !y1 || !xin || !w2 || !wu || !dw2 || !dwu || !da1 || !gin || !bn1_sums || N < 1 || ((sx != nullptr) != (bx != nullptr))) {
+    set_error("upblock_bwd_fused: bad argument"); return MMVAE_ERR_ARG;
+  }
+  if (!join_bwd_stream_ok(DT_BF16, 1, 16, 32, 64)) { set_error("upblock_bwd_fused: disabled (MMVAE_JOIN_BWD_STREAM=0)"); return MMVAE_ERR_UNSUPPORTED; }
+  char* sc = static_cast<char*>(scratch);
+  const ConvGeom g = geom_for(1, 16, 16, 4, 2, 1);
+  int rc = op_pack_down(DT_BF16, g, w2, sc, S(st)); if (rc < 0) return rc;
+  rc = op_pack_down(DT_BF16, g, wu, sc + 8192, S(st)); if (rc < 0) return rc;
+  float* parts = reinterpret_cast<float*>(sc + 16384);
+  JoinBwdLaunch L;
+  L.d_raw = d_raw; L.w_tail = tw; L.y2 = y2; L.ys = ys; L.ms2 = s2; L.mb2 = b2; L.mss = ss; L.mbs = bs;
+  L.A2 = A2; L.B2 = B2; L.C2 = C2; L.As = As; L.Bs = Bs; L.Cs = Cs;
+  L.y1 = y1; L.p1s = s1; L.p1b = b1; L.wd2 = sc; L.da1 = da1; L.part2 = parts; L.bn_part = parts + 2L * 512 * 4096;
+  L.xin = xin; L.pxs = sx; L.pxb = bx; L.wds = sc + 8192; L.gin = gin; L.parts = parts + 512L * 4096;
+  L.N = N;
+  const int nb = launch_join_bwd_stream(L, S(st));
+  if (nb < 0) return nb;
+  for (int k = 0; k < 2; ++k) {
+    WgradReduceArgs u; std::memset(&u, 0, sizeof(u));
+    u.part = k ? L.parts : L.part2; u.dW = k ? dwu : dw2; u.Ca = 16; u.Cb = 16; u.ntaps = 16; u.nparts = nb;
+    u.Ca_valid = 16; u.Cb_valid = 16; u.sA = 16 * 16; u.sB = 16; u.scale = 1.f;
+    for (int t = 0; t < 16; ++t) u.tap_off[t] = t;
+    rc = launch_wgrad_reduce(u, S(st)); if (rc < 0) return rc;
+  }
+  return launch_partial_rowsum(L.bn_part, nb, 32, bn1_sums, S(st));
+}
+int mmvae_conv1x1_bwd_fused(const void* da1, const void* y1, const float* s1, const float* b1, const float* A1, const float* B1, const float* C1,
+                            const void* xin, const float* sx, const float* bx, const float* w1, float* dw1, void* gin, int64_t rows, void* scratch,
+                            void* st) {
+  if (!scratch || !da1 || !y1 || !s1 || !b1 || !A1 || !B1 || !C1 || !xin || !w1 || !dw1 || !gin || rows < 1 || ((sx != nullptr) != (bx != nullptr))) {
+    set_error("conv1x1_bwd_fused: bad argument"); return MMVAE_ERR_ARG;
+  }
+  char* sc = static_cast<char*>(scratch);
+  const ConvGeom g = geom_for(0, 16, 16, 1, 1, 0);
+  int rc = op_pack_up(DT_BF16, g, w1, sc, S(st)); if (rc < 0) return rc;
+  Conv1BwdLaunch C;
+  C.da1 = da1; C.y1 = y1; C.ms = s1; C.mb = b1; C.A = A1; C.B = B1; C.C = C1; C.xin = xin; C.pxs = sx; C.pxb = bx; C.w1u = sc; C.gin = gin;
+  C.part = reinterpret_cast<float*>(sc + 4096); C.nrows = (long)rows;
+  const int nb = launch_conv1_bwd_stream(C, S(st));
+  if (nb < 0) return nb;
+  WgradReduceArgs u; std::memset(&u, 0, sizeof(u));
+  u.part = C.part; u.dW = dw1; u.Ca = 16; u.Cb = 16; u.ntaps = 1; u.nparts = nb; u.Ca_valid = 16; u.Cb_valid = 16; u.sA = 16; u.sB = 1; u.scale = 1.f;
+  return launch_wgrad_reduce(u, S(st));
+}
 int mmvae_convert(int di, int dout, const void* in, void* out, int64_t n, void* st) { return launch_convert(di, dout, in, out, (long)n, S(st)); }
 
 }  // extern "C"

@@ -181,3 +181,83 @@ def test_tail_join_bwd(shape, dt, wgrad):
     for got, want in ((dy2, r2), (dys, rs)):
         err = ((got.float().cpu().permute(0, 3, 1, 2) - want).abs().max() / want.abs().max()).item()
         assert err < tol, (shape, dt, "apply", err)
+
+
+@pytest.mark.parametrize("N", [1, 3, 19])
+@pytest.mark.parametrize("pro_x", [False, True])
+def test_upblock_backward_in_one_pass(N, pro_x):
+    """mmvae_upblock_bwd_fused + mmvae_conv1x1_bwd_fused (conv_joinbwd.hip) against the composition they replace, every piece of which
+    has its own parity test: mmvae_tail_join_bwd_apply (dy2, dys stored) -> mmvae_convT_bwd_fused over dy2 (conv2) and over dys
+    (upsample, with conv1's share x2 (x) w2 and conv1's weight gradient).  The fused pass rounds the dy rows to bf16 in LDS as the
+    stored tensors are, and multiplies in the same order: the data gradients agree element for element (up to rare last-bit differences
+    of a dy value before its rounding), the weight gradients up to that and the grouping of their f32 partial sums.  bn1's backward sums against torch (from the f32 data gradient the kernel holds)."""
+    L = _lib()
+    lib = L.lib()
+    g = torch.Generator().manual_seed(500 + N)
+    H, W = 64, 64
+    bf = lambda t: t.to(torch.bfloat16).float()
+    y2, ys = bf(torch.randn(N, 16, H, W, generator=g)), bf(torch.randn(N, 16, H, W, generator=g))
+    vec = lambda lo, hi: torch.rand(16, generator=g) * (hi - lo) + lo
+    s2, ss, b2, bs = vec(0.5, 1.5), vec(0.5, 1.5), vec(-0.3, 0.3), vec(-0.3, 0.3)
+    A2, B2, C2, As, Bs, Cs = vec(0.5, 1.5), vec(-0.05, 0.05), vec(-0.02, 0.02), vec(0.5, 1.5), vec(-0.05, 0.05), vec(-0.02, 0.02)
+    tw = torch.randn(1, 16, 3, 3, generator=g) / 12.0
+    d_raw = torch.randn(N, 1, H, W, generator=g)
+    y1, xin = bf(torch.randn(N, 16, 32, 32, generator=g)), bf(torch.randn(N, 16, 32, 32, generator=g))
+    s1, b1 = vec(0.5, 1.5), vec(-0.3, 0.3)
+    sx, bx = (vec(0.5, 1.5), vec(-0.3, 0.3)) if pro_x else (None, None)
+    w2, wu = torch.randn(16, 16, 4, 4, generator=g) / 8.0, torch.randn(16, 16, 4, 4, generator=g) / 8.0
+    w1 = torch.randn(16, 16, 1, 1, generator=g) / 4.0
+    A1, B1, C1 = vec(0.5, 1.5), vec(-0.05, 0.05), vec(-0.02, 0.02)
+    st = torch.cuda.current_stream().cuda_stream
+    cu = lambda t: None if t is None else t.cuda()
+    nh = lambda t: _nhwc(t, "bf16")
+    y2d, ysd, y1d, xind = nh(y2), nh(ys), nh(y1), nh(xin)
+    dv = {k: cu(v) for k, v in dict(s2=s2, ss=ss, b2=b2, bs=bs, A2=A2, B2=B2, C2=C2, As=As, Bs=Bs, Cs=Cs, tw=tw, d_raw=d_raw, s1=s1, b1=b1, sx=sx, bx=bx,
+                                      w2=w2, wu=wu, w1=w1, A1=A1, B1=B1, C1=C1).items()}
+    P = L.ptr
+    big = lambda: torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    # ---- reference composition
+    dy2 = torch.empty(N, H, W, 16, device="cuda", dtype=torch.bfloat16)
+    dys = torch.empty_like(dy2)
+    L.check(lib.mmvae_tail_join_bwd_apply(1, P(dv["d_raw"]), P(dv["tw"]), 1, P(y2d), P(dv["s2"]), P(dv["b2"]), P(ysd), P(dv["ss"]), P(dv["bs"]),
+                                          P(dv["A2"]), P(dv["B2"]), P(dv["C2"]), P(dv["As"]), P(dv["Bs"]), P(dv["Cs"]), P(dy2), P(dys), N, H, W, st), "apply")
+    dw2_r, dwu_r, dw1_r = torch.zeros(16, 16, 4, 4, device="cuda"), torch.zeros(16, 16, 4, 4, device="cuda"), torch.zeros(16, 16, device="cuda")
+    da1_r = torch.empty(N, 32, 32, 16, device="cuda", dtype=torch.bfloat16)
+    gin_r = torch.empty_like(da1_r)
+    sc, wsc = torch.empty(65536, dtype=torch.uint8, device="cuda"), big()
+    L.check(lib.mmvae_convT_bwd_fused(1, P(y1d), P(dy2), P(dv["w2"]), P(dw2_r), P(da1_r), N, 32, 32, 16, 16, 4, 2, 1, P(dv["s1"]), P(dv["b1"]), 1,
+                                      None, None, None, P(sc), P(wsc), st), "c2")
+    # dy1 from the reference d_a1 (torch, bf16-rounded like the kernel's LDS row)
+    da1_f = da1_r.float().cpu().permute(0, 3, 1, 2)
+    v4 = lambda t: t.view(1, -1, 1, 1)
+    m1 = (y1 * v4(s1) + v4(b1)) > 0
+    dy1 = bf(v4(A1) * (da1_f * m1) + v4(B1) * y1 + v4(C1))
+    dy1d = nh(dy1)
+    w1t = w1.view(16, 16).t().contiguous().cuda()            # the (Cin, 16) form mmvae_convT_bwd_fused takes for w2
+    L.check(lib.mmvae_convT_bwd_fused(1, P(xind), P(dys), P(dv["wu"]), P(dwu_r), P(gin_r), N, 32, 32, 16, 16, 4, 2, 1, P(dv["sx"]), P(dv["bx"]), 1,
+                                      P(dy1d), P(w1t), P(dw1_r), P(sc), P(wsc), st), "cs")
+    # ---- the one-pass form
+    dw2_f, dwu_f, dw1_f = torch.zeros_like(dw2_r), torch.zeros_like(dwu_r), torch.zeros(16, 16, 1, 1, device="cuda")
+    da1_f2 = torch.full((N, 32, 32, 16), float("nan"), device="cuda", dtype=torch.bfloat16)
+    gin_f = torch.full((N, 32, 32, 16), float("nan"), device="cuda", dtype=torch.bfloat16)
+    sums = torch.full((2, 16), float("nan"), device="cuda")
+    wsc2 = big()
+    L.check(lib.mmvae_upblock_bwd_fused(P(dv["d_raw"]), P(dv["tw"]), P(y2d), P(dv["s2"]), P(dv["b2"]), P(ysd), P(dv["ss"]), P(dv["bs"]), P(dv["A2"]),
+                                        P(dv["B2"]), P(dv["C2"]), P(dv["As"]), P(dv["Bs"]), P(dv["Cs"]), P(y1d), P(dv["s1"]), P(dv["b1"]), P(dv["w2"]),
+                                        P(dw2_f), P(da1_f2), P(sums), P(xind), P(dv["sx"]), P(dv["bx"]), P(dv["wu"]), P(dwu_f), P(gin_f), N, P(wsc2),
+                                        st), "upblock_bwd_fused")
+    L.check(lib.mmvae_conv1x1_bwd_fused(P(da1_f2), P(y1d), P(dv["s1"]), P(dv["b1"]), P(dv["A1"]), P(dv["B1"]), P(dv["C1"]), P(xind), P(dv["sx"]),
+                                        P(dv["bx"]), P(dv["w1"]), P(dw1_f), P(gin_f), N * 32, P(wsc2), st), "conv1x1_bwd_fused")
+    torch.cuda.synchronize()
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    # (the two kernels contract a*g + b*y + c into FMAs independently: a last-bit difference of a dy element before its bf16 rounding is
+    # possible, so "almost every element equal, the rest one bf16 step apart" instead of torch.equal)
+    neq = (da1_f2 != da1_r).float().mean().item()
+    assert neq < 2e-3 and rel(da1_f2.float(), da1_r.float()) < 1e-2, (neq, rel(da1_f2.float(), da1_r.float()))
+    assert rel(dw2_f, dw2_r) < 1e-4 and rel(dwu_f, dwu_r) < 1e-4, (rel(dw2_f, dw2_r), rel(dwu_f, dwu_r))
+    # g_in: the two-pass form adds conv1's share inside the MFMA accumulator, the one-pass form rounds the shortcut's share to bf16 first
+    assert rel(gin_f.float(), gin_r.float()) < 1.2e-2
+    assert rel(dw1_f.view(16, 16), dw1_r) < 1e-3, rel(dw1_f.view(16, 16), dw1_r)
+    gm = da1_r.float().cpu().permute(0, 3, 1, 2) * m1
+    ref_sums = torch.stack([gm.sum((0, 2, 3)), (gm * y1).sum((0, 2, 3))])
+    assert ((sums.cpu() - ref_sums).abs().max() / ref_sums.abs().max()).item() < 1e-2
