@@ -93,6 +93,13 @@ MMVAE_API int mmvae_decoder_fwd(mmvae_net* net, int N, const float* encoding, co
                       void* workspace, size_t workspace_bytes, float* recon, int training, void* stream);
 MMVAE_API int mmvae_decoder_bwd(mmvae_net* net, int N, const float* d_recon, const float* params, float* grads, void* workspace,
                       size_t workspace_bytes, float* d_encoding /* may be NULL */, void* stream);
+/* The same with the Gaussian reconstruction loss folded in (reference model.py:403, VAE.loss with decoder_out_channels == in_channels):
+ * the gradient entering the decoder is d_recon = coef / sigma^2 * gscale[0] * (recon - target), recon being the reconstruction the last
+ * mmvae_decoder_fwd on this workspace returned (full size, before any crop).  It is evaluated inside the output BatchNorm's backward
+ * from the saved conv output and `target` [N,out_ch,S,S] f32 -- no d_recon tensor, two passes over the plane instead of four.
+ * gscale: device scalar (the upstream gradient of the loss), nullable (= 1). */
+MMVAE_API int mmvae_decoder_bwd_gauss(mmvae_net* net, int N, const float* target, float sigma, float coef, const float* gscale, const float* params,
+                            float* grads, void* workspace, size_t workspace_bytes, float* d_enc, void* stream);
 
 /* Weight gradients run on a side stream owned by the net.  By default every backward entry point orders
  * them before `stream` again when it returns.  mmvae_net_defer_join(net, 1): mmvae_decoder_bwd leaves its weight gradients in

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "mmvae_encoder_bwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P]),
     "mmvae_decoder_fwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P, c_int, P]),
     "mmvae_decoder_bwd": (c_int, [P, c_int, P, P, P, P, c_size_t, P, P]),
+    "mmvae_decoder_bwd_gauss": (c_int, [P, c_int, P, c_float, c_float, P, P, P, P, c_size_t, P, P]),
     "mmvae_net_defer_join": (c_int, [P, c_int]),
     "mmvae_net_join": (c_int, [P, P]),
     "mmvae_net_set_sync_bn": (c_int, [P, P, P, c_int]),

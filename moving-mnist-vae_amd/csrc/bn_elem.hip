@@ -1306,6 +1306,92 @@ int launch_affine_nchw(const float* raw, const float* scale, const float* shift,
   hipLaunchKernelGGL(affine_nchw_kernel, dim3(blocks), dim3(256), 0, s, raw, scale, shift, out, total, C, HW);
   return check_launch("affine_nchw");
 }
+// ---- Gaussian reconstruction loss fused into the output BatchNorm's backward (reference model.py:193, :403): the loss gradient
+//   d[n,c,i] = k * (scale[c] * raw[n,c,i] + shift[c] - target[n,c,i]),  k = coef / sigma^2 (* the upstream gradient, a device scalar)
+// is a function of the conv output `raw` and the target alone, so neither d_recon nor a second read of recon is needed: the reduce pass
+// sums (d, d * raw) per channel straight from raw and target, the apply pass writes d_raw = A d + B raw + C.  Two passes over the plane
+// (2 reads each, 1 write) instead of gauss_nll_bwd + plane_reduce + apply (6 reads, 2 writes).  Same block / summation structure as
+// plane_reduce_nchw_kernel (bit-reproducible).
+__global__ __launch_bounds__(256) void gauss_tail_reduce_kernel(const float* __restrict__ raw, const float* __restrict__ tgt, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float k, const float* __restrict__ gs, int N, int C,
+                                                                 int HW, float* __restrict__ partials) {
+  extern __shared__ float sm[];
+  float* sAcc = sm;             // [4 waves][2][C]
+  const int wid = threadIdx.x >> 6;
+  if (gs) k *= gs[0];
+  for (int i = threadIdx.x; i < 4 * 2 * C; i += blockDim.x) sAcc[i] = 0.f;
+  __syncthreads();
+  const int planes = N * C;
+  for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+    const int c = p % C;
+    const float sc = scale[c], sh = shift[c];
+    const float* pa = raw + (long)p * HW;
+    const float* pt = tgt + (long)p * HW;
+    float v0 = 0.f, v1 = 0.f;
+    if ((HW & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < HW; i += 4 * blockDim.x) {
+        const float4 x = *reinterpret_cast<const float4*>(pa + i);
+        const float4 t = *reinterpret_cast<const float4*>(pt + i);
+        const float d0 = k * ((sc * x.x + sh) - t.x), d1 = k * ((sc * x.y + sh) - t.y), d2 = k * ((sc * x.z + sh) - t.z), d3 = k * ((sc * x.w + sh) - t.w);
+        v0 += (d0 + d1) + (d2 + d3);
+        v1 += (d0 * x.x + d1 * x.y) + (d2 * x.z + d3 * x.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float x = pa[i], d = k * ((sc * x + sh) - pt[i]);
+        v0 += d; v1 += d * x;
+      }
+    }
+    v0 = wave_sum(v0); v1 = wave_sum(v1);
+    if ((threadIdx.x & 63) == 0) { sAcc[wid * 2 * C + c] += v0; sAcc[wid * 2 * C + C + c] += v1; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x)
+    partials[(long)blockIdx.x * 2 * C + i] = (sAcc[i] + sAcc[2 * C + i]) + (sAcc[2 * 2 * C + i] + sAcc[3 * 2 * C + i]);
+}
+int launch_gauss_tail_reduce(const float* raw, const float* target, const float* scale, const float* shift, float sigma, float coef, const float* gscale,
+                             int N, int C, int HW, float* partials, hipStream_t s) {
+  const int blocks = nchw_parts(N, C);
+  const size_t sm = (size_t)4 * 2 * C * sizeof(float);
+  hipLaunchKernelGGL(gauss_tail_reduce_kernel, dim3(blocks), dim3(256), sm, s, raw, target, scale, shift, coef / (sigma * sigma), gscale, N, C, HW, partials);
+  const int rc = check_launch("gauss_tail_reduce");
+  return rc ? rc : blocks;
+}
+__global__ __launch_bounds__(256) void gauss_tail_apply_kernel(const float* __restrict__ raw, const float* __restrict__ tgt, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float k, const float* __restrict__ gs,
+                                                                const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cc,
+                                                                float* __restrict__ dy, int planes, int C, int HW) {
+  if (gs) k *= gs[0];
+  for (int p = blockIdx.x; p < planes; p += gridDim.x) {
+    const int c = p % C;
+    const float sc = scale[c], sh = shift[c], ca = A[c], cb = B[c], cc = Cc[c];
+    const long base = (long)p * HW;
+    if ((HW & 3) == 0) {
+      for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+        const float4 x = *reinterpret_cast<const float4*>(raw + base + i);
+        const float4 t = *reinterpret_cast<const float4*>(tgt + base + i);
+        float4 o;
+        o.x = ca * (k * ((sc * x.x + sh) - t.x)) + cb * x.x + cc; o.y = ca * (k * ((sc * x.y + sh) - t.y)) + cb * x.y + cc;
+        o.z = ca * (k * ((sc * x.z + sh) - t.z)) + cb * x.z + cc; o.w = ca * (k * ((sc * x.w + sh) - t.w)) + cb * x.w + cc;
+        *reinterpret_cast<float4*>(dy + base + i) = o;
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        const float x = raw[base + i];
+        dy[base + i] = ca * (k * ((sc * x + sh) - tgt[base + i])) + cb * x + cc;
+      }
+    }
+  }
+}
+int launch_gauss_tail_apply(const float* raw, const float* target, const float* scale, const float* shift, float sigma, float coef, const float* gscale,
+                            const float* A, const float* B, const float* Cc, float* dy, int N, int C, int HW, hipStream_t s) {
+  if (C > 64) { set_error("gauss_tail_apply: C=%d > 64", C); return MMVAE_ERR_UNSUPPORTED; }
+  const int planes = N * C;
+  const int blocks = planes < 4096 ? planes : 4096;
+  hipLaunchKernelGGL(gauss_tail_apply_kernel, dim3(blocks), dim3(256), 0, s, raw, target, scale, shift, coef / (sigma * sigma), gscale, A, B, Cc, dy, planes, C, HW);
+  return check_launch("gauss_tail_apply");
+}
+
 // dy = A[c]*dout + B[c]*y + C[c] on NCHW f32 planes.  Block = whole planes (n, c).
 __global__ __launch_bounds__(256) void bn_bwd_apply_nchw_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                                 const float* __restrict__ A, const float* __restrict__ B,

@@ -89,6 +89,13 @@ int mmvae_decoder_bwd(mmvae_net* n, int N, const float* d_recon, const float* pa
   return n->net->decoder_bwd(N, d_recon, params, grads, ws, wsb, d_enc, S(stream));
 }
 
+int mmvae_decoder_bwd_gauss(mmvae_net* n, int N, const float* target, float sigma, float coef, const float* gscale, const float* params, float* grads,
+                            void* ws, size_t wsb, float* d_enc, void* stream) {
+  if (!n || N <= 0 || !target || !params || !grads || !ws || !(sigma > 0.f)) { set_error("decoder_bwd_gauss: bad argument"); return MMVAE_ERR_ARG; }
+  const Net::GaussTail gt{target, sigma, coef, gscale};
+  return n->net->decoder_bwd(N, nullptr, params, grads, ws, wsb, d_enc, S(stream), &gt);
+}
+
 int mmvae_net_defer_join(mmvae_net* n, int enable) {
   if (!n) { set_error("net_defer_join: bad argument"); return MMVAE_ERR_ARG; }
   n->net->set_defer_join(enable != 0);
@@ -380,8 +387,8 @@ int mmvae_upblock_bwd_fused(const float* d_raw, const float* tw, const void* y2,
   JoinBwdLaunch L;
   L.d_raw = d_raw; L.w_tail = tw; L.y2 = y2; L.ys = ys; L.ms2 = s2; L.mb2 = b2; L.mss = ss; L.mbs = bs;
   L.A2 = A2; L.B2 = B2; L.C2 = C2; L.As = As; L.Bs = Bs; L.Cs = Cs;
-  L.y1 = y1; L.p1s = s1; L.p1b = b1; L.wd2 = sc; L.da1 = da1; L.part2 = parts; L.bn_part = parts + 2L * 512 * 4096;
-  L.xin = xin; L.pxs = sx; L.pxb = bx; L.wds = sc + 8192; L.gin = gin; L.parts = parts + 512L * 4096;
+  L.y1 = y1; L.p1s = s1; L.p1b = b1; L.wd2 = sc; L.da1 = da1; L.part2 = parts; L.bn_part = parts + 2L * 1024 * 4096;
+  L.xin = xin; L.pxs = sx; L.pxb = bx; L.wds = sc + 8192; L.gin = gin; L.parts = parts + 1024L * 4096;
   L.N = N;
   const int nb = launch_join_bwd_stream(L, S(st));
   if (nb < 0) return nb;

@@ -46,8 +46,8 @@ struct JoinBwdArgs {
 // (the one-wave-per-strip form needed the whole 512-register file and ran at 2.3 TB/s).  Two block barriers per step order the
 // pair's LDS traffic: [d_raw rows, P rows] -> barrier -> [produce] -> barrier -> [consume]; the loads of the next step are in flight
 // during the consume phase.  A block = two pairs; every pair runs the same number of steps (idle ones past its last unit).
-template <bool PRO_X>
-__global__ __launch_bounds__(256, 2) void join_bwd_stream_kernel(JoinBwdArgs a) {
+template <bool PRO_X, int PAIRS>
+__global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwdArgs a) {
   constexpr int KS = 4, S = 2, PAD = 1, WP = 32, Wg = 64;
   constexpr int WL = S * (WP - 1) + KS;                    // 66 ring columns: -1 .. 64
   constexpr int ROWB = WL * 32;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void join_bwd_stream_kernel(JoinBwdArgs a) 
   }
   if (role == 0) for (int i = lane; i < 4 * DP; i += 64) dring[i] = 0.f;
   // ---- block-shared A fragments of the two data gradients: [conv][pair of taps][lane]
-  for (int i = t; i < 2 * (NT / 2) * 64; i += 256) {
+  for (int i = t; i < 2 * (NT / 2) * 64; i += 128 * PAIRS) {
     const int ln = i & 63, pr = (i >> 6) % (NT / 2), cv = (i >> 6) / (NT / 2);
     const char* wd = reinterpret_cast<const char*>(cv ? a.wds : a.wd2);
     reinterpret_cast<Vec16*>(smem)[i] = *reinterpret_cast<const Vec16*>(wd + (ln & 15) * (NT * 32) + pr * 64 + (ln >> 4) * 16);
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void join_bwd_stream_kernel(JoinBwdArgs a) 
   if ((nblk & 7) == 0) {
     const int per = (a.nunits + 7) >> 3;
     const int lo = (blockIdx.x & 7) * per;
-    u_first = lo + (blockIdx.x >> 3) * 2 + pair; u_step = (nblk >> 3) * 2; u_end = min(a.nunits, lo + per);
-  } else { u_first = blockIdx.x * 2 + pair; u_step = nblk * 2; u_end = a.nunits; }
+    u_first = lo + (blockIdx.x >> 3) * PAIRS + pair; u_step = (nblk >> 3) * PAIRS; u_end = min(a.nunits, lo + per);
+  } else { u_first = blockIdx.x * PAIRS + pair; u_step = nblk * PAIRS; u_end = a.nunits; }
   const int nq = a.Hp + 1;                                  // the priming step + one per P row
   // units of the block's first pair >= units of its second: the first pair's count bounds both
   int my_units = 0, max_units = 0;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void join_bwd_stream_kernel(JoinBwdArgs a) 
   // ---- flush: the two pairs add their accumulators in LDS (pair order), the block stores one partial image per conv
   float* img = reinterpret_cast<float*>(smem);
   __syncthreads();
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < PAIRS; ++p) {
     if (pair == p) {
 #pragma unroll
       for (int k = 0; k < NT; ++k)
@@ -324,11 +324,11 @@ __global__ __launch_bounds__(256, 2) void join_bwd_stream_kernel(JoinBwdArgs a) 
       for (int j = 0; j < 4; ++j) { sb[pair * 32 + 4 * gq + j] = bs0[j]; sb[pair * 32 + 16 + 4 * gq + j] = bs1[j]; }
     }
     __syncthreads();
-    if (t < 32) a.bn_part[(long)blockIdx.x * 32 + t] = sb[t] + sb[32 + t];
+    if (t < 32) a.bn_part[(long)blockIdx.x * 32 + t] = PAIRS == 2 ? sb[t] + sb[32 + t] : sb[t];
   }
   float* dst2 = a.part2 + (long)blockIdx.x * (NT * 256);
   float* dsts = a.parts + (long)blockIdx.x * (NT * 256);
-  for (int i = t; i < NT * 256 / 4; i += 256) {
+  for (int i = t; i < NT * 256 / 4; i += 128 * PAIRS) {
     reinterpret_cast<float4*>(dst2)[i] = reinterpret_cast<const float4*>(img)[i];
     reinterpret_cast<float4*>(dsts)[i] = reinterpret_cast<const float4*>(img + NT * 256)[i];
   }
@@ -349,21 +349,22 @@ int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s) {
   a.xin = L.xin; a.pxs = L.pxs; a.pxb = L.pxb; a.wds = L.wds; a.gin = L.gin; a.parts = L.parts;
   a.N = L.N; a.Hp = 32; a.Hg = 64; a.nunits = L.N;
   if (!L.p1s || !L.p1b) { set_error("join_bwd_stream: conv2's input needs bn1's scale / shift"); return MMVAE_ERR_ARG; }
+  // measured (config 2, ms per step): two pairs per block x 512 blocks 7.17; 384 blocks 7.34; 768 blocks 7.24; one pair per block
+  // (128 threads, 1024 blocks) 9.8 -- its register cap spills the accumulators
+  constexpr int pairs = 2;
   int gx = 512;                                             // two blocks of two wave pairs per CU (LDS: 58 KB each)
-  while (gx > 8 && (long)gx * 2 > a.nunits) gx -= 8;
-  constexpr size_t lds = 2 * 8 * 1024 + 2 * (size_t)(2 * 4 * 66 * 32 + 3 * 1024 + 4 * 68 * 4);
+  while (gx > 8 && (long)gx * pairs > a.nunits) gx -= 8;
+  constexpr size_t lds = 2 * 8 * 1024 + pairs * (size_t)(2 * 4 * 66 * 32 + 3 * 1024 + 4 * 68 * 4);
   static_assert(lds >= 2 * 16 * 256 * 4 + 512, "the flush images alias the rings");
-  auto k0 = &join_bwd_stream_kernel<false>;
-  auto k1 = &join_bwd_stream_kernel<true>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("join_bwd_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
     attr_set = true;
   }
-  if (L.pxs) hipLaunchKernelGGL(k1, dim3(gx), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(k0, dim3(gx), dim3(256), lds, s, a);
+  if (L.pxs) hipLaunchKernelGGL((join_bwd_stream_kernel<true, 2>), dim3(gx), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((join_bwd_stream_kernel<false, 2>), dim3(gx), dim3(256), lds, s, a);
   const int rc = check_launch("join_bwd_stream");
   return rc ? rc : gx;
 }

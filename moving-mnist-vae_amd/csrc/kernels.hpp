@@ -307,6 +307,11 @@ int launch_affine_nchw(const float* raw, const float* scale, const float* shift,
 int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s);
 int launch_bn_bwd_apply_nchw(const float* dout, const float* y, const float* A, const float* B, const float* Cc, float* dy,
                              int N, int C, int HW, hipStream_t s);
+// Gaussian NLL gradient fused into the output BatchNorm's backward: d = coef / sigma^2 * gscale[0] * (scale*raw + shift - target) is never stored
+int launch_gauss_tail_reduce(const float* raw, const float* target, const float* scale, const float* shift, float sigma, float coef, const float* gscale,
+                             int N, int C, int HW, float* partials, hipStream_t s);      // partial rows (sum d, sum d*raw); returns nparts
+int launch_gauss_tail_apply(const float* raw, const float* target, const float* scale, const float* shift, float sigma, float coef, const float* gscale,
+                            const float* A, const float* B, const float* Cc, float* dy, int N, int C, int HW, hipStream_t s);
 
 // ---------------------------------------------------------------- latent / loss
 // enc = mu + exp(0.5*logvar)*eps (f32 and T copies); kl_partial: -0.5*sum(lv - exp(lv) - mu^2 + 1) (one float, atomically added)

@@ -201,7 +201,7 @@ const Plan& Net::plan(int N) {
   P.da1 = take(maxact);
   P.dh = take((long)N * 2 * cfg.z * e);
   P.wscratch = take((long)kWgradScratchBytes);
-  P.wscratch2 = take(512L * (16 * 32 * 16 + 16 * 32) * 4);   // partial images of a fused dgrad+wgrad pass on the caller's stream (512 blocks x ([16][32][16] + [16][32]) f32)
+  P.wscratch2 = take(2L * 1024 * 4096 * 4);           // partial images of the fused passes on the caller's stream: 512 blocks x ([16][32][16] + [16][32]) f32 (wgrad_stream), 2 x 1024 x [16][16][16] (join_bwd_stream)
   P.stem_R = take(1024 * 8);
   P.stem_gram = take(1024L * stem_bwd_part_floats() * 4);
   P.bytes = (size_t)cur;
@@ -856,7 +856,7 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
 }
 
 int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* grads, void* ws, size_t ws_bytes, float* d_enc,
-                     hipStream_t s) {
+                     hipStream_t s, const GaussTail* gauss) {
   const Plan& P = plan(N);
   if (ws_bytes < P.bytes) { set_error("workspace too small"); return MMVAE_ERR_WORKSPACE; }
   char* base = static_cast<char*>(ws);
@@ -869,11 +869,17 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   MM_TRY(packs_dec_bwd(params, base, d_enc != nullptr, s));
   MM_TRY(pack_batch_flush(dt(), s));
   // ---- output BN backward, tail conv backward
-  int np = launch_bn_bwd_reduce_nchw(d_recon, r_raw, N, cfg.out_ch, HW, part, s);
+  int np = gauss ? launch_gauss_tail_reduce(r_raw, gauss->target, bnf(bn_out, base, 2), bnf(bn_out, base, 3), gauss->sigma, gauss->coef, gauss->gscale, N,
+                                            cfg.out_ch, HW, part, s)
+                 : launch_bn_bwd_reduce_nchw(d_recon, r_raw, N, cfg.out_ch, HW, part, s);
   MM_TRY(np);
   // (the tail conv's bias gradient, sum of d_raw per output channel, in closed form from the same sums: BnBwdFinalizeArgs::dbias_conv)
   MM_TRY(bn_backward_coefs(bn_out, params, grads, base, np, 1, 0, (double)N * HW, s, grads + tail_bias));
-  MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
+  if (gauss)
+    MM_TRY(launch_gauss_tail_apply(r_raw, gauss->target, bnf(bn_out, base, 2), bnf(bn_out, base, 3), gauss->sigma, gauss->coef, gauss->gscale,
+                                   bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
+  else
+    MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
   static const bool tail_wgrad_direct = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_DIRECT"); return e && e[0] == '1'; }();
   // one output plane: a tiled VALU reduction (launch_tail_wgrad_tile) beats the MFMA wgrad; MMVAE_TAIL_WGRAD_TILE=0 disables it
   static const bool tail_wgrad_tile_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_TILE"); return !(e && e[0] == '0'); }();
@@ -966,7 +972,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       L.y1 = base + B.y1; L.p1s = bnf(B.b1, base, 2); L.p1b = bnf(B.b1, base, 3);
       L.wd2 = base + plan_.packed + B.c2.packD * (long)esz(); L.da1 = base + P.da1; L.part2 = ws2; L.bn_part = part;
       L.xin = xin; L.pxs = xs; L.pxb = xb; L.wds = base + plan_.packed + B.cs.packD * (long)esz(); L.gin = base + P.g[cur ^ 1];
-      L.parts = ws2 + 512L * 4096;                         // (at most 512 blocks, one [16][16][16] partial image per conv each)
+      L.parts = ws2 + 1024L * 4096;                        // (at most 1024 blocks, one [16][16][16] partial image per conv each)
       L.N = N;
       const int nb = launch_join_bwd_stream(L, s);
       MM_TRY(nb);

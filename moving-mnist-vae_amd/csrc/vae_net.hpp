@@ -89,8 +89,11 @@ class Net {
                   hipStream_t s);
   int decoder_fwd(int N, const float* enc, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
                   float* recon, int training, hipStream_t s);
+  // gauss (optional, then d_recon == NULL): the reconstruction gradient is the Gaussian NLL's, d_recon = coef / sigma^2 * gscale[0] *
+  // (recon - target) with recon the forward's output -- computed inside the output BatchNorm's backward, never stored
+  struct GaussTail { const float* target; float sigma; float coef; const float* gscale; };
   int decoder_bwd(int N, const float* d_recon, const float* params, float* grads, void* ws, size_t ws_bytes, float* d_enc,
-                  hipStream_t s);
+                  hipStream_t s, const GaussTail* gauss = nullptr);
 
  private:
   Plan plan_;

@@ -103,6 +103,7 @@ class _DecoderFn(torch.autograd.Function):
         ctx.model, ctx.N, ctx.training = model, N, training
         ctx.token = model._stamp("dec", training)
         ctx.need_denc = bool(ctx.needs_input_grad[1])
+        model._last_recon = (recon.data_ptr(), ctx.token) if training else None
         return recon
 
     @staticmethod
@@ -110,7 +111,13 @@ class _DecoderFn(torch.autograd.Function):
         model = ctx.model
         model._check_stamp("dec", ctx.token, ctx.training)
         N = ctx.N
-        d_recon = d_recon.contiguous().float()
+        # Gaussian loss tail (see _LossFn.backward): the incoming "gradient" is the loss function's token -- the real one is evaluated
+        # inside the output BatchNorm's backward from the saved conv output and the target, and never stored
+        tail = model._pending_tail
+        model._pending_tail = None
+        fused_tail = (tail is not None and tail[5] == ctx.token and d_recon.stride(0) == 0 and d_recon.data_ptr() == tail[0].data_ptr())
+        if not fused_tail:
+            d_recon = d_recon.contiguous().float()
         d_enc = torch.empty((N, model.z_dimensions, 1, 1), device=d_recon.device, dtype=torch.float32) if ctx.need_denc else None
         G = model._grad_target()
         G[model._dec_off:].zero_()
@@ -122,8 +129,13 @@ class _DecoderFn(torch.autograd.Function):
         # stream is not held up there either.
         defer = _DEFER_JOIN
         check(lib().mmvae_net_defer_join(model._h, int(defer)), "mmvae_net_defer_join")
-        check(lib().mmvae_decoder_bwd(model._h, N, ptr(d_recon), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), ptr(d_enc), _stream()),
-              "mmvae_decoder_bwd")
+        if fused_tail:
+            _, target, sigma, coef, gscale, _ = tail
+            check(lib().mmvae_decoder_bwd_gauss(model._h, N, ptr(target), float(sigma), float(coef), ptr(gscale), ptr(model._flat), ptr(G), ptr(ws),
+                                                ws.numel(), ptr(d_enc), _stream()), "mmvae_decoder_bwd_gauss")
+        else:
+            check(lib().mmvae_decoder_bwd(model._h, N, ptr(d_recon), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), ptr(d_enc), _stream()),
+                  "mmvae_decoder_bwd")
         if defer:
             h, st = model._h, _stream()
             torch.autograd.Variable._execution_engine.queue_callback(lambda: check(lib().mmvae_net_join(h, st), "mmvae_net_join"))
@@ -239,6 +251,10 @@ class _LossFn(torch.autograd.Function):
         check(L.mmvae_loss_finish(base, ptr(out), float(model.nll), float(model.kl), float(model.mmd), float(N), st), "mmvae_loss_finish")
         model._last_scalars = out
         ctx.model, ctx.N, ctx.categorical = model, N, categorical
+        # the reconstruction is the decoder's own output tensor (no crop, no copy): its gradient can be folded into the decoder's backward
+        lr = model._last_recon
+        ctx.direct_tail = (lr[1] if (lr is not None and lr[0] == recon.data_ptr() and not categorical and model.fuse_loss_tail and
+                                     target.dtype == torch.float32 and target.shape == recon.shape) else None)
         ctx.save_for_backward(target, mu, logvar, encoding, recon, true_samples, weight)
         return out[0]
 
@@ -249,8 +265,17 @@ class _LossFn(torch.autograd.Function):
         target, mu, logvar, encoding, recon, ts, weight = ctx.saved_tensors
         st = _stream()
         g = g.contiguous().float()
-        d_recon = torch.empty_like(recon)
-        if ctx.categorical:
+        if ctx.direct_tail is not None and model._stamps.get(("dec", True)) == ctx.direct_tail:
+            # No d_recon tensor: hand the decoder's backward what it needs to evaluate coef / sigma^2 * g * (recon - target) itself, and a
+            # token in place of the gradient -- a 0-strided NaN, so that any OTHER consumer of it fails loudly instead of silently.
+            token = model._tail_token(recon)
+            model._pending_tail = (token, target, float(model.sigma_decoder), float(model.nll) / N, g, ctx.direct_tail)
+            d_recon = token
+        else:
+            d_recon = torch.empty_like(recon)
+        if ctx.direct_tail is not None and d_recon.stride(0) == 0:
+            pass
+        elif ctx.categorical:
             Q, HW = recon.shape[1], recon.shape[2] * recon.shape[3]
             check(L.mmvae_ce_bwd(ptr(recon), ptr(target), ptr(weight), N, Q, HW, float(model.nll) / N, ptr(g), ptr(d_recon), st), "mmvae_ce_bwd")
         else:
@@ -319,6 +344,12 @@ class VAE(nn.Module):
         d["_sync"] = None
         d["_last_scalars"] = None
         d["_last_group"] = None
+        d["_last_recon"] = None            # (data_ptr, forward stamp) of the last train-mode reconstruction
+        d["_pending_tail"] = None          # Gaussian loss gradient handed from _LossFn.backward to _DecoderFn.backward
+        d["_nan_scalar"] = None
+        # Gaussian NLL: fold the loss gradient into the decoder's backward (no d_recon tensor).  Set False when the reconstruction
+        # tensor feeds anything besides VAE.loss in the autograd graph.
+        d["fuse_loss_tail"] = os.environ.get("MMVAE_FUSE_LOSS_TAIL", "1") != "0"
         d["injected_eps"] = None           # parity tests: noise for rsample / loss instead of torch.randn
         d["injected_true_samples"] = None
         d["_ptable"], d["_btable"] = [], []
@@ -453,6 +484,11 @@ class VAE(nn.Module):
             ws = torch.empty(need, dtype=torch.uint8, device=self._flat.device)
             self._ws[training] = ws
         return ws
+
+    def _tail_token(self, like):
+        if self._nan_scalar is None or self._nan_scalar.device != like.device:
+            self.__dict__["_nan_scalar"] = torch.full((1,), float("nan"), device=like.device, dtype=torch.float32)
+        return self._nan_scalar.expand(like.shape)
 
     def _ws_view(self, dev_ptr, n):
         """f32 view of n floats at a device address inside one of this model's workspaces (SyncBN all-reduce operands)."""

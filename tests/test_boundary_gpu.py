@@ -239,3 +239,36 @@ def test_train_step_is_bit_reproducible(oracle, dtype, categorical):
     assert not bad, f"gradients differ between two runs of the same step: {bad[:8]} ({len(bad)} of {len(a[1])})"
     assert torch.equal(a[3], b[3]), "BatchNorm running statistics differ"
     assert torch.equal(a[2], b[2]), "parameters after Adam differ"
+
+
+def test_gaussian_loss_gradient_folded_into_the_decoder_backward(oracle):
+    """VAE.loss's Gaussian NLL gradient is evaluated inside the output BatchNorm's backward (mmvae_decoder_bwd_gauss: no d_recon tensor)
+    when the reconstruction handed to loss() is the decoder's own output; fuse_loss_tail = False, a cropped reconstruction (S = 56) or a
+    reconstruction that went through another op take the materialised path.  Same gradients either way."""
+    import types
+    M = _M()
+    dev = torch.device("cuda")
+    args = types.SimpleNamespace(data_ratio_of_labels=None)
+    for S, N in ((64, 12), (56, 6)):
+        labels = oracle.synthetic_labels(N, S, seed=5)
+        image = oracle.normalise(labels, S).to(dev)
+        g = torch.Generator().manual_seed(9)
+        eps, ts = torch.randn(N, 32, 1, 1, generator=g).to(dev), torch.randn(N, 32, generator=g).to(dev)
+        grads = {}
+        for mode in ("fused", "plain", "through_op"):
+            torch.manual_seed(3)
+            m = M.VAE(1, 32, 1, 2, 32, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, S, compute_dtype="f32").to(dev).train()
+            m.fuse_loss_tail = mode != "plain"
+            m.injected_eps, m.injected_true_samples = eps, ts
+            mu, lv, enc, rec = m(image)
+            if mode == "through_op":
+                rec = rec * 1.0                       # a different tensor: the loss cannot fold its gradient
+            loss = m.loss(image, mu, lv, enc, rec, dev, args)[0]
+            loss.backward()
+            assert m._pending_tail is None
+            grads[mode] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        for k, ref in grads["plain"].items():
+            scale = ref.abs().max().item() + 1e-30
+            for mode in ("fused", "through_op"):
+                err = (grads[mode][k] - ref).abs().max().item()
+                assert err <= 2e-5 * scale + 1e-7, (S, mode, k, err, scale)
