@@ -83,6 +83,15 @@ MMVAE_API size_t mmvae_net_workspace_bytes(mmvae_net* net, int N);
  * momentum 0.1 / unbiased variance and num_batches_tracked += 1 (nn.BatchNorm2d); else running statistics. */
 MMVAE_API int mmvae_encoder_fwd(mmvae_net* net, int N, const float* x, const float* params, float* bn_f32, int64_t* bn_i64,
                       void* workspace, size_t workspace_bytes, float* mu, float* logvar, int training, void* stream);
+/* Input staging (reference main.py:383-387, image = (label - mean) / std): labels (int64 as the reference's loader yields them,
+ * label_bytes = 8, or uint8, label_bytes = 1; N * in_channels * S * S of them) -> `image` f32 [N,in_channels,S,S] (the caller's tensor:
+ * network input and Gaussian-loss target) AND the storage-type copy in the workspace's input slot, in ONE pass.
+ * mmvae_encoder_fwd_staged is mmvae_encoder_fwd for exactly that `image` right after: it skips the conversion pass over x (the caller
+ * guarantees x has not changed since it was staged into this workspace). */
+MMVAE_API int mmvae_net_stage_labels(mmvae_net* net, int N, const void* labels, int label_bytes, float mean, float stdv, float* image,
+                           void* workspace, size_t workspace_bytes, void* stream);
+MMVAE_API int mmvae_encoder_fwd_staged(mmvae_net* net, int N, const float* x, const float* params, float* bn_f32, int64_t* bn_i64,
+                             void* workspace, size_t workspace_bytes, float* mu, float* logvar, int training, void* stream);
 /* autograd of the above (loss.backward(), main.py:398): accumulates (+=) parameter gradients into `grads`
  * (same flat layout as params; caller zeroes).  No gradient is produced for the image. */
 MMVAE_API int mmvae_encoder_bwd(mmvae_net* net, int N, const float* d_mu, const float* d_logvar, const float* params, float* grads,

@@ -27,6 +27,8 @@ PROTOTYPES = {
     "mmvae_net_entry": (c_int, [P, c_int, c_char_p, c_int, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64)]),
     "mmvae_net_workspace_bytes": (c_size_t, [P, c_int]),
     "mmvae_encoder_fwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P, P, c_int, P]),
+    "mmvae_net_stage_labels": (c_int, [P, c_int, P, c_int, c_float, c_float, P, P, c_size_t, P]),
+    "mmvae_encoder_fwd_staged": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P, P, c_int, P]),
     "mmvae_encoder_bwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P]),
     "mmvae_decoder_fwd": (c_int, [P, c_int, P, P, P, P, P, c_size_t, P, c_int, P]),
     "mmvae_decoder_bwd": (c_int, [P, c_int, P, P, P, P, c_size_t, P, P]),

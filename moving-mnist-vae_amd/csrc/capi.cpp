@@ -72,6 +72,18 @@ int mmvae_encoder_fwd(mmvae_net* n, int N, const float* x, const float* params, 
   if (!bn_f32) { set_error("encoder_fwd: BN buffers required"); return MMVAE_ERR_ARG; }
   return n->net->encoder_fwd(N, x, params, bn_f32, reinterpret_cast<long long*>(bn_i64), ws, wsb, mu, logvar, training, S(stream));
 }
+int mmvae_net_stage_labels(mmvae_net* n, int N, const void* labels, int label_bytes, float mean, float stdv, float* image, void* ws, size_t wsb,
+                           void* stream) {
+  if (!n || N <= 0 || !labels || !image || !ws) { set_error("net_stage_labels: bad argument"); return MMVAE_ERR_ARG; }
+  return n->net->stage_labels(N, labels, label_bytes, mean, stdv, image, ws, wsb, S(stream));
+}
+int mmvae_encoder_fwd_staged(mmvae_net* n, int N, const float* x, const float* params, float* bn_f32, int64_t* bn_i64, void* ws, size_t wsb,
+                             float* mu, float* logvar, int training, void* stream) {
+  if (!n || N <= 0 || !x || !params || !ws || !mu) { set_error("encoder_fwd_staged: bad argument"); return MMVAE_ERR_ARG; }
+  if (n->net->cfg.need_logvar && !logvar) { set_error("encoder_fwd_staged: logvar required"); return MMVAE_ERR_ARG; }
+  if (!bn_f32) { set_error("encoder_fwd_staged: BN buffers required"); return MMVAE_ERR_ARG; }
+  return n->net->encoder_fwd(N, x, params, bn_f32, reinterpret_cast<long long*>(bn_i64), ws, wsb, mu, logvar, training, S(stream), true);
+}
 int mmvae_encoder_bwd(mmvae_net* n, int N, const float* d_mu, const float* d_logvar, const float* params, float* grads, void* ws,
                       size_t wsb, void* stream) {
   if (!n || N <= 0 || !d_mu || !params || !grads || !ws) { set_error("encoder_bwd: bad argument"); return MMVAE_ERR_ARG; }
@@ -190,7 +202,7 @@ int mmvae_loss_finish(const double* acc, float* out, float nll, float kl_coef, f
 
 // ---- plumbing
 int mmvae_normalise_labels(const int64_t* labels, int64_t n, float mean, float stdv, float* image, void* st) {
-  return launch_normalise(DT_F32, reinterpret_cast<const long long*>(labels), (long)n, mean, stdv, nullptr, image, S(st));
+  return launch_normalise(DT_F32, labels, 8, (long)n, mean, stdv, nullptr, image, S(st));
 }
 int mmvae_quantise_normalise(const uint8_t* frames, int64_t n, const float* centres, int q, float mean, float stdv, int64_t* labels,
                              float* image, void* st) {

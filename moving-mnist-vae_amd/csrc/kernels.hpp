@@ -341,7 +341,8 @@ struct AdamArgs { float* p; const float* g; float* m; float* v; long n; float lr
 int launch_adam(const AdamArgs& a, hipStream_t s);
 int launch_adam_dev(const AdamArgs& a, double* state, hipStream_t s);   // step count on the device (graph capture): bc1 / bc2 ignored
 // labels (int64) -> image T [(l - mean)/std] (+ f32 copy for the Gaussian target)
-int launch_normalise(int dt, const long long* labels, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s);
+// labels: int64 (label_bytes = 8) or uint8 (1)
+int launch_normalise(int dt, const void* labels, int label_bytes, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s);
 int launch_quantise_normalise(const unsigned char* frames, long n, const float* centres, int q, float mean, float stdv,
                               long long* labels, float* image, hipStream_t s);
 int launch_convert(int dt_in, int dt_out, const void* in, void* out, long n, hipStream_t s);

@@ -509,19 +509,46 @@ int launch_adam_dev(const AdamArgs& a, double* state, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------- input normalisation (main.py:383-387)
-template <typename T>
-__global__ void normalise_kernel(const long long* __restrict__ labels, long n, float mean, float stdv, T* __restrict__ img,
-                                 float* __restrict__ img32) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+// Four labels per thread (32-byte / 4-byte loads, 16-byte f32 store, 8-byte bf16 store); TL = int64 (what the reference's loader yields)
+// or uint8 (a label transport an eighth of the size); both outputs optional.
+template <typename T, typename TL>
+__global__ void normalise_kernel(const TL* __restrict__ labels, long n, float mean, float stdv, T* __restrict__ img, float* __restrict__ img32) {
+  const long nq = n >> 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    float v[4];
+    if constexpr (sizeof(TL) == 8) {
+      const longlong2 a = reinterpret_cast<const longlong2*>(labels)[2 * q], b = reinterpret_cast<const longlong2*>(labels)[2 * q + 1];
+      v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)b.x; v[3] = (float)b.y;
+    } else {
+      const uchar4 a = reinterpret_cast<const uchar4*>(labels)[q];
+      v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)a.z; v[3] = (float)a.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (v[j] - mean) / stdv;
+    if (img32) reinterpret_cast<float4*>(img32)[q] = make_float4(v[0], v[1], v[2], v[3]);
+    if (img) {
+      if constexpr (sizeof(T) == 4) reinterpret_cast<float4*>(img)[q] = make_float4(v[0], v[1], v[2], v[3]);
+      else reinterpret_cast<uint2*>(img)[q] = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+    }
+  }
+  // tail (n not a multiple of 4)
+  for (long i = (nq << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float v = ((float)labels[i] - mean) / stdv;
     if (img) Elem<T>::store(img + i, v);
     if (img32) img32[i] = v;
   }
 }
-int launch_normalise(int dt, const long long* labels, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s) {
+int launch_normalise(int dt, const void* labels, int label_bytes, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s) {
   if (n <= 0) return MMVAE_OK;
-  if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float>), dim3(rblocks(n, 2048)), dim3(256), 0, s, labels, n, mean, stdv, (float*)img_t, img_f32);
-  else hipLaunchKernelGGL((normalise_kernel<bf16_t>), dim3(rblocks(n, 2048)), dim3(256), 0, s, labels, n, mean, stdv, (bf16_t*)img_t, img_f32);
+  if (label_bytes != 8 && label_bytes != 1) { set_error("normalise: labels must be int64 or uint8"); return MMVAE_ERR_ARG; }
+  const dim3 g(rblocks((n >> 2) + 1, 2048)), b(256);
+  if (label_bytes == 8) {
+    if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float, long long>), g, b, 0, s, (const long long*)labels, n, mean, stdv, (float*)img_t, img_f32);
+    else hipLaunchKernelGGL((normalise_kernel<bf16_t, long long>), g, b, 0, s, (const long long*)labels, n, mean, stdv, (bf16_t*)img_t, img_f32);
+  } else {
+    if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float, unsigned char>), g, b, 0, s, (const unsigned char*)labels, n, mean, stdv, (float*)img_t, img_f32);
+    else hipLaunchKernelGGL((normalise_kernel<bf16_t, unsigned char>), g, b, 0, s, (const unsigned char*)labels, n, mean, stdv, (bf16_t*)img_t, img_f32);
+  }
   return check_launch("normalise");
 }
 

@@ -483,8 +483,14 @@ int Net::packs_dec_bwd(const float* params, char* base, bool need_denc, hipStrea
 }
 
 // ------------------------------------------------------------------------------------------------ encoder
+int Net::stage_labels(int N, const void* labels, int label_bytes, float mean, float stdv, float* image, void* ws, size_t ws_bytes, hipStream_t s) {
+  const Plan& P = plan(N);
+  if (ws_bytes < P.bytes) { set_error("workspace too small: %zu < %zu", ws_bytes, P.bytes); return MMVAE_ERR_WORKSPACE; }
+  return launch_normalise(dt(), labels, label_bytes, (long)N * cfg.in_ch * cfg.S * cfg.S, mean, stdv, static_cast<char*>(ws) + P.x_t, image, s);
+}
+
 int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
-                     float* mu, float* logvar, int training, hipStream_t s) {
+                     float* mu, float* logvar, int training, hipStream_t s, bool staged) {
   if (cfg.in_ch != 1) { set_error("encoder: in_channels=%d unsupported (1)", cfg.in_ch); return MMVAE_ERR_UNSUPPORTED; }
   if (Hf > 2) { set_error("encoder: image size %d unsupported (final map %dx%d)", cfg.S, Hf, Wf); return MMVAE_ERR_UNSUPPORTED; }
   const Plan& P = plan(N);
@@ -496,7 +502,7 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   pack_batch_begin();                       // every weight re-pack of this entry point in ONE launch
   MM_TRY(packs_enc_fwd(params, base, s));
   MM_TRY(pack_batch_flush(dt(), s));
-  MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
+  if (!staged) MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
   static const bool stem_direct = [] { const char* e = getenv("MMVAE_STEM_DIRECT"); return e && e[0] == '1'; }();
   if (!stem_direct && cfg.in_ch == 1 && stem_fwd_stream_ok(dt(), S)) {
     const int np = launch_stem_fwd_stream(dt(), base + P.x_t, params + stem.off, base + P.y0, stats, N, S, s);

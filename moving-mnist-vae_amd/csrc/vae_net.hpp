@@ -83,8 +83,12 @@ class Net {
   size_t workspace_bytes(int N);
   const Plan& plan(int N);
 
+  // staged: the storage-type copy of x is already in the workspace (stage_labels wrote it together with x): no conversion pass
   int encoder_fwd(int N, const float* x, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
-                  float* mu, float* logvar, int training, hipStream_t s);
+                  float* mu, float* logvar, int training, hipStream_t s, bool staged = false);
+  // labels (int64 or uint8, N * in_ch * S * S of them) -> image = (label - mean) / std as f32 (the caller's tensor: the network input and the
+  // Gaussian loss target) AND as the storage type straight into the workspace's input slot, one pass (main.py:383-387)
+  int stage_labels(int N, const void* labels, int label_bytes, float mean, float stdv, float* image, void* ws, size_t ws_bytes, hipStream_t s);
   int encoder_bwd(int N, const float* d_mu, const float* d_logvar, const float* params, float* grads, void* ws, size_t ws_bytes,
                   hipStream_t s);
   int decoder_fwd(int N, const float* enc, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,

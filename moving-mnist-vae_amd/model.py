@@ -63,8 +63,13 @@ class _EncoderFn(torch.autograd.Function):
         logvar = torch.empty_like(mu) if model.require_rsample else None
         training = bool(model.training)
         ws = model._workspace(N, training)
-        check(lib().mmvae_encoder_fwd(model._h, N, ptr(x), ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
-                                      ptr(mu), ptr(logvar), int(training), _stream()), "mmvae_encoder_fwd")
+        # prepare_batch staged this very tensor (same storage, untouched since) into this workspace: no conversion pass over x
+        st_ = model._staged
+        staged = st_ is not None and st_[0] == x.data_ptr() and st_[1] == x._version and st_[2] == ws.data_ptr() and st_[3] == N
+        model._staged = None
+        fn = lib().mmvae_encoder_fwd_staged if staged else lib().mmvae_encoder_fwd
+        check(fn(model._h, N, ptr(x), ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
+                 ptr(mu), ptr(logvar), int(training), _stream()), "mmvae_encoder_fwd")
         ctx.model, ctx.N, ctx.training = model, N, training
         ctx.token = model._stamp("enc", training)
         if logvar is None:
@@ -344,6 +349,7 @@ class VAE(nn.Module):
         d["_sync"] = None
         d["_last_scalars"] = None
         d["_last_group"] = None
+        d["_staged"] = None                # (image data_ptr, version, workspace data_ptr, N) of the batch prepare_batch staged
         d["_last_recon"] = None            # (data_ptr, forward stamp) of the last train-mode reconstruction
         d["_pending_tail"] = None          # Gaussian loss gradient handed from _LossFn.backward to _DecoderFn.backward
         d["_nan_scalar"] = None
@@ -625,13 +631,24 @@ class VAE(nn.Module):
     def prepare_batch(self, batch, device, data_mean, data_std, categorical):
         S = self.input_image_size
         labels = batch.to(device)
-        if labels.dtype != torch.int64:
+        if labels.dtype not in (torch.int64, torch.uint8):
             labels = labels.long()
         labels = labels.contiguous()
-        image = torch.empty((labels.numel() // (S * S), 1, S, S), device=labels.device, dtype=torch.float32)
-        check(lib().mmvae_normalise_labels(ptr(labels), labels.numel(), float(data_mean), float(data_std), ptr(image), _stream()),
-              "mmvae_normalise_labels")
-        target = labels.view(-1, S, S) if categorical else image
+        N = labels.numel() // (S * S * self.in_channels)
+        image = torch.empty((N, self.in_channels, S, S), device=labels.device, dtype=torch.float32)
+        self._ensure_flat()
+        # one pass: the f32 image (network input, Gaussian target) and its storage-type copy straight into the workspace the forward
+        # pass is about to use (train() calls the model right after; _EncoderFn checks that it really is this tensor, unmodified)
+        ws = self._workspace(N, bool(self.training))
+        check(lib().mmvae_net_stage_labels(self._h, N, ptr(labels), labels.element_size(), float(data_mean), float(data_std), ptr(image), ptr(ws),
+                                           ws.numel(), _stream()), "mmvae_net_stage_labels")
+        self.__dict__["_staged"] = (image.data_ptr(), image._version, ws.data_ptr(), N)
+        if categorical:
+            target = labels.view(-1, S, S)
+            if target.dtype != torch.int64:
+                target = target.long()
+        else:
+            target = image
         return image, target
 
     def __repr__(self):

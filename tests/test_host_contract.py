@@ -126,6 +126,37 @@ def test_clips_from_npz_array_layout(pkg):
 
 
 @pytest.mark.gpu
+def test_prepare_batch_stages_the_input_once(pkg, oracle):
+    """prepare_batch (main.py:383-387) writes the f32 image AND its storage-type copy into the workspace in one pass; the forward that
+    follows skips its conversion pass only for exactly that tensor.  uint8 labels (an eighth of the int64 transport) give the same image;
+    a modified or foreign input goes through the conversion again; results are identical to the bit."""
+    M = importlib.import_module("moving-mnist-vae_amd.model")
+    dev = torch.device("cuda")
+    labels = oracle.synthetic_labels(6, 64, seed=21).view(6, 4096)
+    torch.manual_seed(2)
+    m = M.VAE(1, 32, 1, 2, 32, False, False, compute_dtype="bf16").to(dev).train()
+    m.injected_eps = torch.randn(6, 32, 1, 1, device=dev)
+    image, target = m.prepare_batch(labels, dev, oracle.DATA_MEAN, oracle.DATA_STD, False)
+    assert target is image and m._staged is not None
+    ref = ((labels.float() - oracle.DATA_MEAN) / oracle.DATA_STD).view(6, 1, 64, 64)
+    assert (image.cpu() - ref).abs().max().item() <= 1e-6
+    out_staged = [t.detach().clone() for t in m(image)]
+    assert m._staged is None                                  # consumed
+    out_plain = [t.detach().clone() for t in m(image.clone())]       # a different tensor: converted by the forward itself
+    for a, b in zip(out_staged, out_plain):
+        assert torch.equal(a, b)
+    image8, _ = m.prepare_batch(labels.to(torch.uint8), dev, oracle.DATA_MEAN, oracle.DATA_STD, False)
+    assert torch.equal(image8, image)
+    image8.mul_(2.0)                                          # touched after staging: the staged copy is stale and must not be used
+    out_mod = m(image8)
+    out_ref = m((image * 2.0))
+    for a, b in zip(out_mod, out_ref):
+        assert torch.equal(a, b)
+    imgc, tgt = m.prepare_batch(labels.to(torch.uint8), dev, oracle.DATA_MEAN, oracle.DATA_STD, True)
+    assert tgt.dtype == torch.int64 and tuple(tgt.shape) == (6, 64, 64)
+
+
+@pytest.mark.gpu
 def test_moving_mnist_clips_loader(pkg, tmp_path):
     """npz on disk -> device-resident clips -> batches of k-means labels shaped like the reference loader's (B, C*H*W)."""
     rng = np.random.default_rng(1)
