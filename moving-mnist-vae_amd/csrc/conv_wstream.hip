@@ -311,14 +311,28 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
             }
           }
         }
-        bf16_t* drow = reinterpret_cast<bf16_t*>(a.dx) + (((long)n * a.Hp + hrow) * WP) * CA + 4 * gq;
+        if constexpr (CA16 == 1) {
+          // a pixel's 32 bytes come from its four gq lanes: whole 32-byte sectors
+          bf16_t* drow = reinterpret_cast<bf16_t*>(a.dx) + (((long)n * a.Hp + hrow) * WP) * CA + 4 * gq;
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-          for (int at = 0; at < CA16; ++at) {
-            float v[4] = {dacc[at][pt][0], dacc[at][pt][1], dacc[at][pt][2], dacc[at][pt][3]};
-            dstore4<bf16_t>(drow + (16 * pt + r) * CA + 16 * at, v, false);
+          for (int pt = 0; pt < 2; ++pt) {
+            float v[4] = {dacc[0][pt][0], dacc[0][pt][1], dacc[0][pt][2], dacc[0][pt][3]};
+            dstore4<bf16_t>(drow + (16 * pt + r) * CA, v, false);
           }
+        } else {
+          // 32 channels: a lane's two quads are 32 bytes apart -- through the (now free) P rows in LDS, then whole 16-byte vectors
+          bf16_t* stg = reinterpret_cast<bf16_t*>(prow) + 4 * gq;
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int at = 0; at < CA16; ++at) {
+              float v[4] = {dacc[at][pt][0], dacc[at][pt][1], dacc[at][pt][2], dacc[at][pt][3]};
+              dstore4<bf16_t>(stg + (16 * pt + r) * CA + 16 * at, v, false);
+            }
+          char* dbase = reinterpret_cast<char*>(a.dx) + (((long)n * a.Hp + hrow) * WP) * CAB;
+#pragma unroll
+          for (int k = 0; k < PV; ++k) *reinterpret_cast<Vec16*>(dbase + (lane + 64 * k) * 16) = *reinterpret_cast<const Vec16*>(prow + (lane + 64 * k) * 16);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
