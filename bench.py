@@ -11,9 +11,11 @@ A "step" is one pass of this repo's ``train`` loop body (main.py:371-399 restate
 resident in HBM: labels -> normalise -> forward -> loss -> zero_grad -> backward -> FusedAdam.step.  The four scalars of
 every step (loss, nll, kl, mmd) stay on the device and are read back once, inside the timed region, when ``train``
 returns its per-step lists -- the host never waits for the GPU in the middle of a step.  Prints ONE JSON line (rank 0).
-Besides the contract's keys the line carries ``roofline`` (the dominant kernel family's largest instance, isolated launches
-timed with events on the launch stream), ``roofline_largest_launch`` (the single longest launch of the step, same method),
-``step_hbm_roofline`` (whole step against the ideal-fusion byte count) and ``cpu_baseline`` (the CPU oracle on a bounded sample).
+Besides the contract's keys the line carries ``roofline`` (the largest kernel family of the step by GPU time -- wgrad2_kernel -- at its
+slowest layer, isolated launches timed with events on the launch stream), ``roofline_largest_launch`` (the single longest launch of the
+step, join_bwd_stream_kernel, same method), ``top_kernels`` (the committed per-family table: ms per step, algorithmic and measured bytes),
+``step_hbm_roofline`` (whole step against the ideal-fusion byte count), ``config4_deeper`` / ``config5_fp8`` (short runs of BASELINE
+configs[3] / [4]) and ``cpu_baseline`` (the CPU oracle on a bounded sample).
 """
 import argparse
 import importlib
@@ -32,6 +34,7 @@ PKG = "moving-mnist-vae_amd"
 METRIC = "frames/sec/GPU VAE train step, 20×64×64 batch; ELBO vs CPU ref"
 DATA_MEAN, DATA_STD, P_ON = 0.0521, 0.2222, 0.0521
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 TRAIN_BYTES_PER_FRAME = 3.40e6  # ideal-fusion bf16 activation traffic of one train step, per frame
 TRAIN_FLOP_PER_FRAME = 227409920  # z=128, SURVEY.md section 8(d)
 C4_TRAIN_FLOP_PER_FRAME = {512: 409862144}   # tools/count_flops.py: z=512, 2 blocks per stage (forward 137 166 848)
@@ -145,81 +148,147 @@ def pmc_traffic(kernel_key, N):
     return None, None
 
 
-def dominant_kernel_roofline(M, device, N, reps=20):
-    """HBM roofline of the dominant kernel class, measured live with events on the launch stream: the streaming
-    ConvTranspose2d forward at the decoder's widest layer (decoder.uplayer5.0.conv2, ConvTranspose2d 16->16 k4 s2, 32^2 -> 64^2).
-    Algorithmic bytes per launch = input + output activations (bf16) + weights, each touched once."""
+def committed_top_kernels(N):
+    """The step's kernel families (launches, ms per step, stream, algorithmic MB as declared by the launchers, measured HBM MB, in-step
+    TB/s, traffic ratio) and its twelve longest launches, from the newest profiles/*_top_kernels.json (tools/top_kernels.py: rocprofv3
+    kernel trace + launch census + per-dispatch PMC table of one run).  `same_build` says whether it was taken on this source hash."""
+    import glob
     L = importlib.import_module(PKG + "._lib")
-    lib = L.lib()
-    Cin = Cout = 16
-    H = 32
-    x = torch.randn(N, H, H, Cin, device=device).to(torch.bfloat16)
-    w = torch.randn(Cin, Cout, 4, 4, device=device) * 0.1
-    y = torch.empty(N, 2 * H, 2 * H, Cout, device=device, dtype=torch.bfloat16)
-    scratch = torch.empty(2 * w.numel() * 2 + 256, dtype=torch.uint8, device=device)
-    stats = torch.zeros(4096 * 2 * Cout, device=device)
-    st = torch.cuda.current_stream().cuda_stream
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_top_kernels.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if int(d.get("frames", -1)) != N:
+            continue
+        d["source"] = os.path.relpath(path, ROOT)
+        d["same_build"] = d.get("build") == L.build_hash()
+        return d
+    return None
 
-    def launch(weights=None):
-        L.check(lib.mmvae_conv2d_fwd(1, 1, L.ptr(x), L.ptr(weights), L.ptr(y), N, H, H, Cin, Cout, 4, 2, 1, None, None, 0, L.ptr(stats),
-                                     L.ptr(scratch), st), "conv2d_fwd")
-    launch(w)                  # packs the weights into `scratch`; the timed launches below are the conv kernel alone
-    for _ in range(3):
-        launch()
+
+def _time_calls(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        launch()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    alg = x.numel() * 2 + y.numel() * 2 + w.numel() * 2
-    ach = alg / (ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic("uplayer5.conv2.fwd", N)
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": src,
-            "kernel": "convT4_stream_kernel<32> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16->16 k4 s2, 32x32 -> 64x64; per-wave stream: input-row ring in LDS, 2x2 taps x 16 channels per MFMA K-step, 16-byte stores; isolated launches, cold input)",
-            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
+    return e0.elapsed_time(e1) / reps
+
+
+# The layers whose weight gradient runs on wgrad2_kernel in the step (the others: uplayer5 inside join_bwd_stream_kernel, uplayer4 and
+# encoder.layer1's 3x3 convs on wgrad_stream_kernel, the stem / tail / heads on their own kernels):
+# name, transposed, Cin, Cout, k, stride, pad, H (input side of the forward op), BatchNorm+ReLU prologue on x
+WGRAD2_LAYERS = [
+    ("encoder.layer1.0.downsample.0", 0, 32, 32, 1, 2, 0, 32, 1),
+    ("encoder.layer2.0.conv1", 0, 32, 64, 3, 2, 1, 16, 0), ("encoder.layer2.0.conv2", 0, 64, 64, 3, 1, 1, 8, 1),
+    ("encoder.layer2.0.downsample.0", 0, 32, 64, 1, 2, 0, 16, 0),
+    ("encoder.layer3.0.conv1", 0, 64, 128, 3, 2, 1, 8, 0), ("encoder.layer3.0.conv2", 0, 128, 128, 3, 1, 1, 4, 1),
+    ("encoder.layer3.0.downsample.0", 0, 64, 128, 1, 2, 0, 8, 0),
+    ("encoder.layer4.0.conv1", 0, 128, 256, 3, 2, 1, 4, 0), ("encoder.layer4.0.conv2", 0, 256, 256, 3, 1, 1, 2, 1),
+    ("encoder.layer4.0.downsample.0", 0, 128, 256, 1, 2, 0, 4, 0),
+    ("decoder.uplayer1.0.conv1", 0, 128, 128, 1, 1, 0, 2, 1), ("decoder.uplayer1.0.conv2", 1, 128, 128, 4, 2, 1, 2, 1),
+    ("decoder.uplayer1.0.upsample.0", 1, 128, 128, 4, 2, 1, 2, 1),
+    ("decoder.uplayer2.0.conv1", 0, 128, 64, 1, 1, 0, 4, 0), ("decoder.uplayer2.0.conv2", 1, 64, 64, 4, 2, 1, 4, 1),
+    ("decoder.uplayer2.0.upsample.0", 1, 128, 64, 4, 2, 1, 4, 0),
+    ("decoder.uplayer3.0.conv1", 0, 64, 32, 1, 1, 0, 8, 0), ("decoder.uplayer3.0.conv2", 1, 32, 32, 4, 2, 1, 8, 1),
+    ("decoder.uplayer3.0.upsample.0", 1, 64, 32, 4, 2, 1, 8, 0),
+]
+
+
+def dominant_kernel_roofline(M, device, N, reps=10):
+    """`roofline`: the kernel family with the most GPU time per step in the committed kernel statistics (profiles/*_top_kernels.json) is
+    wgrad2_kernel, the weight gradient of the channel-heavy layers (20 launches, side stream).  Every layer that runs on it is timed
+    in isolation through the C ABI (mmvae_conv2d_wgrad: kernel + partial-image reduce, events on the launch stream), the SLOWEST one is
+    the family's largest instance and is reported against the roofline that bounds it: algorithmic bytes = x + dy (bf16) + the weight
+    gradient (f32), flops = 2 * pixels * Cin * Cout * k^2; bound = mfma when flops / bytes exceeds the bf16 ridge (2.5 PF / 8 TB/s)."""
+    L = importlib.import_module(PKG + "._lib")
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    wsc = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    rows = []
+    for name, tr, Cin, Cout, k, sd, p, H, pro in WGRAD2_LAYERS:
+        Ho = (H - 1) * sd - 2 * p + k if tr else (H + 2 * p - k) // sd + 1
+        x = torch.randn(N, H, H, Cin, device=device).to(torch.bfloat16)
+        dy = torch.randn(N, Ho, Ho, Cout, device=device).to(torch.bfloat16)
+        dw = torch.zeros((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device=device)
+        sc, sh = torch.rand(Cin, device=device) + 0.5, torch.randn(Cin, device=device) * 0.1
+
+        def fn():
+            L.check(lib.mmvae_conv2d_wgrad(1, tr, L.ptr(x), L.ptr(dy), L.ptr(dw), N, H, H, Cin, Cout, k, sd, p, L.ptr(sc) if pro else None,
+                                           L.ptr(sh) if pro else None, 1, L.ptr(wsc), st), name)
+        ms = _time_calls(fn, 4, warm=1)
+        pix = N * (H * H if tr else Ho * Ho)
+        rows.append(dict(layer=name, ms=ms, bytes=(x.numel() + dy.numel()) * 2 + dw.numel() * 4, flop=2.0 * pix * Cin * Cout * k * k))
+        del x, dy, dw
+    worst = max(rows, key=lambda r: r["ms"])
+    name = worst["layer"]
+    spec = next(l for l in WGRAD2_LAYERS if l[0] == name)
+    _, tr, Cin, Cout, k, sd, p, H, pro = spec
+    Ho = (H - 1) * sd - 2 * p + k if tr else (H + 2 * p - k) // sd + 1
+    x = torch.randn(N, H, H, Cin, device=device).to(torch.bfloat16)
+    dy = torch.randn(N, Ho, Ho, Cout, device=device).to(torch.bfloat16)
+    dw = torch.zeros((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device=device)
+    sc, sh = torch.rand(Cin, device=device) + 0.5, torch.randn(Cin, device=device) * 0.1
+    ms = _time_calls(lambda: L.check(lib.mmvae_conv2d_wgrad(1, tr, L.ptr(x), L.ptr(dy), L.ptr(dw), N, H, H, Cin, Cout, k, sd, p, L.ptr(sc) if pro else None,
+                                                            L.ptr(sh) if pro else None, 1, L.ptr(wsc), st), name), reps)
+    alg, flop = worst["bytes"], worst["flop"]
+    gbs, tfs = alg / (ms * 1e-3) / 1e9, flop / (ms * 1e-3) / 1e12
+    mfma_bound = flop / alg > MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    top = committed_top_kernels(N)
+    fam = None if top is None else next((f for f in top["families"] if f["family"] == "wgrad2_kernel"), None)
+    return {"bound": "mfma" if mfma_bound else "hbm", "achieved": tfs if mfma_bound else gbs, "peak": MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tfs / MFMA_PEAK_TFLOPS) if mfma_bound else (gbs / HBM_PEAK_GBS),
+            "traffic": None, "traffic_source": None,
+            "kernel": f"wgrad2_kernel (+ wgrad_reduce_kernel) @ {name}: weight gradient of {'ConvTranspose2d' if tr else 'Conv2d'}({Cin} -> {Cout}, k{k} s{sd} p{p}) "
+                      f"on {H}x{H} inputs, the slowest of the {len(WGRAD2_LAYERS)} layers of the step's largest kernel family by GPU time "
+                      "(isolated mmvae_conv2d_wgrad calls: tap-split MFMA tiles, per-block partial images, ordered reduce)",
+            "algorithmic_bytes_per_launch": alg, "algorithmic_flop_per_launch": flop, "avg_launch_ms": ms,
+            "achieved_GBs": gbs, "achieved_TFLOPs": tfs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "frac_of_mfma_peak": tfs / MFMA_PEAK_TFLOPS,
+            "family_in_step": fam, "family_layers_isolated_ms": {r["layer"]: round(r["ms"], 4) for r in rows},
+            "family_isolated_ms_sum": sum(r["ms"] for r in rows)}
 
 
 def largest_launch_roofline(M, device, N, reps=10):
-    """Second roofline object: the single longest launch of the step, the last up-block's join-backward apply pass
-    (tail_apply_mfma_kernel): reads the two branch outputs, recomputes the incoming gradient from the 1-plane
-    d_raw, writes dy2 / dys.  Algorithmic bytes per launch = 4 x (N*64*64*16 bf16) + d_raw once (f32)."""
+    """Second roofline object: the single longest launch of the step, join_bwd_stream_kernel -- the last up-block's backward in one pass
+    (conv_joinbwd.hip): reads the two branch outputs (671 MB each at N = 5120), the one-plane reconstruction gradient and the two
+    32x32 operands, writes the two 32x32 data gradients; dy2 / dys never exist.  Timed through mmvae_upblock_bwd_fused (events around the
+    call: the kernel plus two weight packs, two partial-image reduces and one row sum, ~25 us of small launches)."""
     L = importlib.import_module(PKG + "._lib")
     lib = L.lib()
-    H = 64
     bf = torch.bfloat16
-    y2 = torch.randn(N, H, H, 16, device=device).to(bf)
-    ys = torch.randn(N, H, H, 16, device=device).to(bf)
-    dy2, dys = torch.empty_like(y2), torch.empty_like(ys)
-    d_raw = torch.randn(N, 1, H, H, device=device)
-    w = torch.randn(1, 16, 3, 3, device=device) * 0.1
-    co = [torch.rand(16, device=device) + 0.5 for _ in range(10)]
+    y2, ys = torch.randn(N, 64, 64, 16, device=device).to(bf), torch.randn(N, 64, 64, 16, device=device).to(bf)
+    y1, xin = torch.randn(N, 32, 32, 16, device=device).to(bf), torch.randn(N, 32, 32, 16, device=device).to(bf)
+    da1, gin = torch.empty_like(y1), torch.empty_like(xin)
+    d_raw = torch.randn(N, 1, 64, 64, device=device)
+    tw = torch.randn(1, 16, 3, 3, device=device) * 0.1
+    w2, wu = torch.randn(16, 16, 4, 4, device=device) * 0.1, torch.randn(16, 16, 4, 4, device=device) * 0.1
+    dw2, dwu = torch.zeros_like(w2), torch.zeros_like(wu)
+    co = [torch.rand(16, device=device) + 0.5 for _ in range(12)]
+    sums = torch.zeros(2, 16, device=device)
+    wsc = torch.empty(64 << 20, dtype=torch.uint8, device=device)
     st = torch.cuda.current_stream().cuda_stream
+    P = L.ptr
 
     def launch():
-        L.check(lib.mmvae_tail_join_bwd_apply(1, L.ptr(d_raw), L.ptr(w), 1, L.ptr(y2), L.ptr(co[0]), L.ptr(co[1]), L.ptr(ys), L.ptr(co[2]),
-                                              L.ptr(co[3]), L.ptr(co[4]), L.ptr(co[5]), L.ptr(co[6]), L.ptr(co[7]), L.ptr(co[8]), L.ptr(co[9]),
-                                              L.ptr(dy2), L.ptr(dys), N, H, H, st), "tail_join_bwd_apply")
-    for _ in range(2):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    alg = 4 * y2.numel() * 2 + d_raw.numel() * 4
+        L.check(lib.mmvae_upblock_bwd_fused(P(d_raw), P(tw), P(y2), P(co[0]), P(co[1]), P(ys), P(co[2]), P(co[3]), P(co[4]), P(co[5]), P(co[6]), P(co[7]),
+                                            P(co[8]), P(co[9]), P(y1), P(co[10]), P(co[11]), P(w2), P(dw2), P(da1), P(sums), P(xin), None, None, P(wu),
+                                            P(dwu), P(gin), N, P(wsc), st), "upblock_bwd_fused")
+    ms = _time_calls(launch, reps)
+    alg = 2 * y2.numel() * 2 + d_raw.numel() * 4 + 4 * y1.numel() * 2
     ach = alg / (ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic("uplayer5.join_bwd_apply", N)
+    traffic, src = pmc_traffic("uplayer5.join_bwd", N)
+    top = committed_top_kernels(N)
+    inst = None if top is None else next((k for k in top["largest"] if "join_bwd_stream_kernel" in k["kernel"]), None)
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": src,
-            "kernel": "tail_apply_mfma_kernel @ decoder.uplayer5 join backward (apply pass) fused with the decoder.conv2 dgrad (isolated launches)",
-            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms}
+            "kernel": "join_bwd_stream_kernel @ decoder.uplayer5: join BatchNorm backward + both ConvTranspose2d weight / data gradients + bn1 sums in one "
+                      "pass, fused with the decoder.conv2 dgrad (isolated mmvae_upblock_bwd_fused calls, helper launches included)",
+            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "in_step": inst}
 
 
 def step_traffic(N):
@@ -362,11 +431,44 @@ def main():
         torch.cuda.synchronize()
         d256 = (time.perf_counter() - t1) / 20
         out["batch256_frames"] = {"frames_per_sec": 256 / d256, "ms_per_step": 1e3 * d256, "note": "256 frames (not clips) per step"}
+    if world == 1 and not a.no_roofline and a.config == "c2" and a.dtype == "bf16":
+        # compact records of BASELINE configs[3] (deeper net, z = 512, 512 clips) and configs[4] (fp8 mode of config 2) in the default line,
+        # a few steps each (the full runs: --config c4, --dtype fp8)
+        del model, opt
+        torch.cuda.empty_cache()
+
+        def sub_record(dtype, blocks_, z_, clips_, steps_):
+            torch.manual_seed(0)
+            m2 = M.VAE(1, 32, 1, 2, z_, False, False, 4, "ReLu", 1, 1, 0, True, 0.1, 64, compute_dtype=dtype, blocks_per_stage=blocks_).to(device).train()
+            o2 = M.FusedAdam(list(m2.parameters()))
+            b2 = synthetic_clips(clips_, 4321, device)
+            pkg.train(m2, [b2] * 3, o2, device, args, data_mean=DATA_MEAN, data_std=DATA_STD)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            ls = pkg.train(m2, [b2] * steps_, o2, device, args, data_mean=DATA_MEAN, data_std=DATA_STD)[0]
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t2) / steps_
+            del m2, o2, b2
+            torch.cuda.empty_cache()
+            return d2, ls[-1]
+
+        d4, l4 = sub_record("bf16", 2, 512, 512, 5)
+        fl4 = C4_TRAIN_FLOP_PER_FRAME[512]
+        out["config4_deeper"] = {"ms_per_step": 1e3 * d4, "frames_per_sec": 10240 / d4, "frames": 10240, "steps": 5, "final_loss": l4,
+                                 "achieved_TFLOPs": 10240 / d4 * fl4 / 1e12, "frac_of_2.5PF": 10240 / d4 * fl4 / 2.5e15,
+                                 "note": "BASELINE configs[3]: 2 residual blocks per stage, z=512, 512 clips x 20 frames, bf16"}
+        d5, l5 = sub_record("fp8", 1, a.z, a.clips, 10)
+        out["config5_fp8"] = {"ms_per_step": 1e3 * d5, "frames_per_sec": frames / d5, "steps": 10, "final_loss": l5,
+                              "vs_bf16_same_run": (1e3 * dt / a.steps) / (1e3 * d5),
+                              "note": "BASELINE configs[4]: compute_dtype=fp8 (e4m3 MFMA in the forward convs of the >= 64-channel layers, bf16 storage)"}
     if rank == 0:
         if not a.no_roofline and a.config == "c2":
             out["roofline"] = dominant_kernel_roofline(M, device, frames)
             if a.dtype == "bf16":
                 out["roofline_largest_launch"] = largest_launch_roofline(M, device, frames)
+            top = committed_top_kernels(frames)
+            out["top_kernels"] = None if top is None else {"source": top["source"], "same_build": top["same_build"], "step_ms_traced": top["step_ms_traced"],
+                                                           "hbm_GB": top.get("hbm_GB"), "families": top["families"][:12], "largest": top["largest"][:6]}
             out["elbo_rel_err_vs_cpu_oracle"] = elbo_check(M, device, a.dtype)
         if world == 1 and not a.no_cpu_baseline and a.config == "c2":
             out["cpu_baseline"] = cpu_baseline(a.z)

@@ -258,6 +258,7 @@ static int launch_affine_join_t(const void* a, const float* sa, const float* ba,
   const int blocks = elem_blocks(nvec, threads);
   if (b) hipLaunchKernelGGL((affine_join_kernel<T, true>), dim3(blocks), dim3(threads), 0, s, (const T*)a, sa, ba, (const T*)b, sb, bb, relu, (T*)out, nvec, C);
   else hipLaunchKernelGGL((affine_join_kernel<T, false>), dim3(blocks), dim3(threads), 0, s, (const T*)a, sa, ba, (const T*)nullptr, sb, bb, relu, (T*)out, nvec, C);
+  note_launch_bytes((double)npix * C * sizeof(T) * (b ? 3 : 2));
   return check_launch("affine_join");
 }
 
@@ -333,6 +334,7 @@ static int launch_bn_bwd_reduce_t(const void* dout, const void* out, const float
   if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else if (mode == 3) MMVAE_LAUNCH(2, 3); else MMVAE_LAUNCH(2, 2); }
   else { if (mode == 0) MMVAE_LAUNCH(1, 0); else if (mode == 1) MMVAE_LAUNCH(1, 1); else MMVAE_LAUNCH(1, 2); }
 #undef MMVAE_LAUNCH
+  note_launch_bytes((double)npix * C * sizeof(T) * (1 + ny + (out ? 1 : 0)));
   int rc = check_launch("bn_bwd_reduce");
   return rc ? rc : blocks;
 }
@@ -443,6 +445,7 @@ static int launch_bn_bwd_apply_t(const void* dout, const void* out, const float*
   if (ny == 2) { if (mode == 0) MMVAE_LAUNCH(2, 0); else if (mode == 1) MMVAE_LAUNCH(2, 1); else if (mode == 3) MMVAE_LAUNCH(2, 3); else MMVAE_LAUNCH(2, 2); }
   else { if (mode == 0) MMVAE_LAUNCH(1, 0); else if (mode == 1) MMVAE_LAUNCH(1, 1); else MMVAE_LAUNCH(1, 2); }
 #undef MMVAE_LAUNCH
+  note_launch_bytes((double)npix * C * sizeof(T) * (1 + 2 * ny + (out ? 1 : 0)));
   return check_launch("bn_bwd_apply");
 }
 int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* msk_scale, const float* msk_shift,
@@ -996,6 +999,7 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
       const int tf = ((pt / W + 2) * (W + 2) + 3) & ~3;
       hipLaunchKernelGGL(tail_apply_mfma_kernel, dim3(nb), dim3(256), (size_t)2 * tf * sizeof(float), s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, A0, B0, C0,
                          (bf16_t*)dy0, (const bf16_t*)y1, A1, B1, C1, (bf16_t*)dy1);
+      note_launch_bytes((double)N * H * W * (4 * 16 * 2.0 + 4.0));
       const int rcm = check_launch("tail_apply_mfma");
       return rcm ? rcm : nb;
     }
@@ -1007,6 +1011,7 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
       const int tf = ((pt / W + 2) * (W + 2) + 3) & ~3;
       const size_t lds = ((size_t)4 * (tf + 8) + 4 * 512 + 192 + 576) * sizeof(float);
       hipLaunchKernelGGL(tail_reduce_mfma_kernel, dim3(nb), dim3(256), lds, s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, (const bf16_t*)y1, partials, wpartials);
+      note_launch_bytes((double)N * H * W * (2 * 16 * 2.0 + 4.0));
       const int rcm = check_launch("tail_reduce_mfma");
       return rcm ? rcm : nb;
     }
@@ -1304,6 +1309,7 @@ int launch_affine_nchw(const float* raw, const float* scale, const float* shift,
   const long total = (long)N * C * HW;
   const int blocks = elem_blocks(total / 4 + 1, 256);
   hipLaunchKernelGGL(affine_nchw_kernel, dim3(blocks), dim3(256), 0, s, raw, scale, shift, out, total, C, HW);
+  note_launch_bytes((double)total * 8.0);
   return check_launch("affine_nchw");
 }
 // ---- Gaussian reconstruction loss fused into the output BatchNorm's backward (reference model.py:193, :403): the loss gradient
@@ -1354,6 +1360,7 @@ int launch_gauss_tail_reduce(const float* raw, const float* target, const float*
   const int blocks = nchw_parts(N, C);
   const size_t sm = (size_t)4 * 2 * C * sizeof(float);
   hipLaunchKernelGGL(gauss_tail_reduce_kernel, dim3(blocks), dim3(256), sm, s, raw, target, scale, shift, coef / (sigma * sigma), gscale, N, C, HW, partials);
+  note_launch_bytes((double)N * C * HW * 8.0);
   const int rc = check_launch("gauss_tail_reduce");
   return rc ? rc : blocks;
 }
@@ -1389,6 +1396,7 @@ int launch_gauss_tail_apply(const float* raw, const float* target, const float* 
   const int planes = N * C;
   const int blocks = planes < 4096 ? planes : 4096;
   hipLaunchKernelGGL(gauss_tail_apply_kernel, dim3(blocks), dim3(256), 0, s, raw, target, scale, shift, coef / (sigma * sigma), gscale, A, B, Cc, dy, planes, C, HW);
+  note_launch_bytes((double)N * C * HW * 12.0);
   return check_launch("gauss_tail_apply");
 }
 

@@ -132,5 +132,7 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* smem) {
 // ---- error plumbing (host); the MMVAE_* codes come from the public header
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// algorithmic bytes (every operand touched once) of the launch the next check_launch() closes -- recorded by the launch census only
+void note_launch_bytes(double bytes);
 
 }  // namespace mmvae

@@ -198,6 +198,7 @@ int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const 
   if (stride == 2) { if (wsc) { if (pro) MMVAE_C3(2, true, true); else MMVAE_C3(2, true, false); } else { if (pro) MMVAE_C3(2, false, true); else MMVAE_C3(2, false, false); } }
   else { if (pro) MMVAE_C3(1, false, true); else MMVAE_C3(1, false, false); }
 #undef MMVAE_C3
+  note_launch_bytes((double)N * 32 * 2.0 * ((double)a.Hi * a.Hi + (double)Ho * Ho * (wsc ? 2 : 1)));
   const int rc = check_launch("conv3_stream");
   return rc ? rc : gx;
 }
@@ -486,6 +487,7 @@ int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const
   const size_t lds = 1024 + 4 * (size_t)(4 * (Hin + 2) * 32 + 2 * Hin * 32);
   if (Hin == 32) { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<32, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<32, false>), dim3(gx), dim3(256), lds, s, a); }
   else { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<16, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<16, false>), dim3(gx), dim3(256), lds, s, a); }
+  note_launch_bytes((double)N * 16 * 2.0 * 5.0 * Hin * Hin);                 // x + y = (1 + 4) Hin^2 pixels of 16 bf16 channels
   const int rc = check_launch("convT4_stream");
   return rc ? rc : gx;
 }
@@ -507,6 +509,7 @@ int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float*
   while (gx > 1 && (long)gx * 4 > a.nunits) gx -= gx > 8 ? 8 : 1;
   const size_t lds = 64 + 4 * (size_t)(4 * 66 * 32);
   hipLaunchKernelGGL(tail_fwd_stream_kernel, dim3(gx), dim3(256), lds, s, a);
+  note_launch_bytes((double)N * H * W * (2 * 16 * 2.0 + 4.0));
   const int rc = check_launch("tail_fwd_stream");
   return rc ? rc : gx;
 }

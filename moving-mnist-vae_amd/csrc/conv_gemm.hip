@@ -624,6 +624,9 @@ static int launch_x2_separately(int dt, int out_dt, const GatherArgs& a, hipStre
 
 int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   const int VE = dt == DT_F32 ? 4 : 8;
+  note_launch_bytes((double)a.N * ((double)a.Hi * a.Wi * (a.x_planar ? a.x_planes : a.Cin) * (a.x_planar == 1 ? 4 : dtype_size(dt)) +
+                                   (double)a.Ho * a.Wo * (a.y_planes > 0 ? a.y_planes : a.Cout) * (a.y_planes > 0 ? 4 : dtype_size(out_dt)) +
+                                   (a.x2 ? (double)a.phases[0].Hq * a.phases[0].Wq * a.Cin2 * dtype_size(dt) : 0.0)));
   if (a.fp8) {
     // fp8 forward convolutions exist in the deep-layer kernel only (the packed weights are e4m3 bytes: no other kernel can read them)
     if (dt != DT_BF16 || out_dt != DT_BF16 || a.x2 || a.accumulate) { set_error("gather_gemm: fp8 needs the bf16 forward path"); return MMVAE_ERR_UNSUPPORTED; }
@@ -960,6 +963,8 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
     return MMVAE_ERR_UNSUPPORTED;
   }
   a.M = a.N * a.Hp * a.Wp;
+  note_launch_bytes((double)a.N * ((double)a.Hp * a.Wp * (a.P_planar ? a.P_planes * 4.0 : a.Ca * (double)dtype_size(dt)) +
+                                   (double)a.Hg * a.Wg * (a.G_planar ? 1 : a.Cb) * (double)dtype_size(dt)));
   if (a.Cb_valid <= 0 || a.Cb_valid > a.Cb) a.Cb_valid = a.Cb;
   if (a.Ca_valid <= 0 || a.Ca_valid > a.Ca) a.Ca_valid = a.Ca;
   if (a.M <= 0) return MMVAE_OK;

@@ -40,6 +40,13 @@ struct JoinBwdArgs {
   int nunits;                                           // N: one unit = one image, all Hp rows
 };
 
+// Measured and NOT kept: a third ring with dy2 - bf16(dy2) and a second set of data-gradient MFMAs on it (hi/lo split of dy2 for conv2's
+// data gradient).  bn1's backward sums are the remainder of a sum that cancels almost completely (BatchNorm-backward outputs have zero
+// mean), and the bf16 rounding of 21 M dy2 elements is 35 % / 58 % of bn1's dgamma / dbeta at config 2's size at initialisation (3 % /
+// 10 % after 60 steps); with hi + lo: 10 % / 19 % -- at +0.12 ms per step (7.13 -> 7.25), for an error that is below the gradient's
+// own minibatch sampling noise either way (tests/test_config2_gpu.py).  Doing the lo part on only half of d_a1's pixels made things
+// worse downstream: sums and applied tensor must stay consistent.
+//
 // Two waves share a strip (a "pair"): both PRODUCE -- wave 0 the first, wave 1 the second of the step's two new dy rows, for both
 // branches, into the pair's two rings -- then wave 0 consumes the dy2 ring (conv2: weight gradient, d_a1, bn1 sums) and wave 1 the dys
 // ring (upsample: weight gradient, its share of the block-input gradient).  64 accumulators per wave instead of 128: two waves per SIMD
@@ -363,6 +370,7 @@ int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s) {
     if (e != hipSuccess) { set_error("join_bwd_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
     attr_set = true;
   }
+  note_launch_bytes((double)L.N * (2.0 * 64 * 64 * 16 * 2 + 64 * 64 * 4.0 + 4.0 * 32 * 32 * 16 * 2));   // y2, ys, d_raw; y1, xin, d_a1, g_in
   if (L.pxs) hipLaunchKernelGGL((join_bwd_stream_kernel<true, 2>), dim3(gx), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((join_bwd_stream_kernel<false, 2>), dim3(gx), dim3(256), lds, s, a);
   const int rc = check_launch("join_bwd_stream");
@@ -472,6 +480,7 @@ int launch_conv1_bwd_stream(const Conv1BwdLaunch& L, hipStream_t s) {
   a.w1u = L.w1u; a.gin = L.gin; a.part = L.part; a.nrows = L.nrows;
   int gx = 1024;
   while (gx > 8 && (long)gx * 4 > a.nrows) gx -= 8;
+  note_launch_bytes((double)L.nrows * 1024.0 * 5);         // d_a1, y1, xin, g_in read; g_in written
   if (L.pxs) hipLaunchKernelGGL(conv1_bwd_stream_kernel<true>, dim3(gx), dim3(256), 4 * 2048, s, a);
   else hipLaunchKernelGGL(conv1_bwd_stream_kernel<false>, dim3(gx), dim3(256), 4 * 2048, s, a);
   const int rc = check_launch("conv1_bwd_stream");

@@ -106,6 +106,7 @@ int launch_wgrad_reduce(WgradReduceArgs a, hipStream_t s) {
   const long wsize = (long)a.ntaps * a.Ca * a.Cb;
   if (wsize % 256) { set_error("wgrad_reduce: %ld elements not a multiple of 256", wsize); return MMVAE_ERR_ARG; }
   a.exclusive = 1;
+  note_launch_bytes((double)a.nparts * a.part_stride * 4.0);
   // elements per block: 256 .. 32 (whole 128-byte lines per part), aiming at >= 256 blocks
   int lanes = 64;
   while (lanes > 8 && wsize / (4 * lanes) < 256) lanes >>= 1;

@@ -500,6 +500,7 @@ int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx,
   const int gx = wstream_fill(a, b, kind, x2 != nullptr);
   if (gx <= 0) return 0;
   b.wd = wd; b.dx = dx; b.x2 = x2; b.w2 = w2; b.bn_part = bn_part;
+  note_launch_bytes((double)a.N * 2.0 * ((double)a.Hp * a.Wp * (2 * a.Ca + (x2 ? 16 : 0)) + (double)a.Hg * a.Wg * a.Cb));     // P, dx, x2, G (bf16)
   const bool pp = a.proP_scale != nullptr;
   int rc;
 #define MMVAE_WSD(WP, CA)                                                                                                    \

@@ -434,6 +434,7 @@ int launch_stem_fwd_stream(int dt, const void* x, const float* w, void* y, float
   if (gx * 4 > a.nslabs) gx = (a.nslabs + 3) / 4;
   const size_t lds = 1024 + 4 * (size_t)a.prow * a.pw * 4;
   hipLaunchKernelGGL(stem_fwd_stream_kernel, dim3(gx), dim3(256), lds, s, a);
+  note_launch_bytes((double)N * ((double)S * S * 2.0 + (double)(S / 2) * (S / 2) * 32 * 2.0));
   const int rc = check_launch("stem_fwd_stream");
   return rc ? rc : gx;
 }
@@ -469,6 +470,7 @@ int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const 
   if (gx < 1) { set_error("stem_bwd: partials buffer too small"); return MMVAE_ERR_WORKSPACE; }
   if (dt == DT_F32) hipLaunchKernelGGL((stem_bwd_kernel<float, 0>), dim3(gx), dim3(256), stem_lds(a, dt), s, a);
   else hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 0>), dim3(gx), dim3(256), stem_lds(a, dt), s, a);
+  note_launch_bytes((double)N * ((double)S * S * 2.0 + 2.0 * Ho * Wo * 32 * 2.0));     // x, g, y0
   const int rc = check_launch("stem_bwd");
   return rc ? rc : gx;
 }

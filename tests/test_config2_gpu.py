@@ -34,12 +34,18 @@ if ROOT not in sys.path:
 pytestmark = pytest.mark.gpu
 
 CLIPS, FRAMES_PER_CLIP, Z, S = 256, 20, 128, 64
-REL_L2_MAX = 0.45        # per parameter tensor: |g_bf16 - g_f32| / |g_f32|   (measured at init: 0.03 .. 0.36)
-COS_MIN = 0.90           # per parameter tensor: cosine(g_bf16, g_f32)         (measured at init: 0.94 .. 1.00)
-REL_L2_MAX_BN1_LAST = 0.80   # decoder.uplayer5.0.bn1.{weight,bias}: sums of a masked gradient that cancels to ~0 (measured 0.36 / 0.63)
-COS_MIN_BN1_LAST = 0.75
-NOISE_RATIO_MAX = 0.5    # |g_bf16 - g_f32| <= 0.5 * |g_f32(batch B) - g_f32(batch A)| / sqrt(2), per tensor (0.75 for the two tensors above;
-                         # measured: <= 0.62 at init, <= 0.25 after 60 steps, where the worst tensor is at 21 % / cosine 0.979)
+REL_L2_MAX = 0.36        # per parameter tensor at initialisation: |g_bf16 - g_f32| / |g_f32|   (measured: 0.03 .. 0.347)
+COS_MIN = 0.93           # per parameter tensor at initialisation: cosine(g_bf16, g_f32)         (measured: 0.938 .. 1.00)
+REL_L2_MAX_TRAINED = 0.25    # after 60 Adam steps, every tensor, no exception (measured: <= 0.223)
+COS_MIN_TRAINED = 0.97
+# decoder.uplayer5.0.bn1.{weight,bias} AT INITIALISATION ONLY: sums over 21 M pixels of a masked data gradient that cancels to ~0
+# (BatchNorm-backward outputs have zero mean); the bf16 rounding of dy2 is 0.35 / 0.58 of them (0.03 / 0.10 after 60 steps).  A hi/lo
+# split of dy2 brings them to 0.10 / 0.19 and costs 0.12 ms per step (csrc/conv_joinbwd.hip): not taken, the error is below the
+# gradient's own minibatch sampling noise (ratio 0.58).
+REL_L2_MAX_BN1_LAST = 0.65
+COS_MIN_BN1_LAST = 0.85
+NOISE_RATIO_MAX = 0.5    # |g_bf16 - g_f32| <= 0.5 * |g_f32(batch B) - g_f32(batch A)| / sqrt(2), per tensor (0.65 for the two tensors above at
+                         # initialisation; measured: <= 0.42 (0.58 for those two) at init, <= 0.28 after 60 steps)
 TRAJ_REL = 0.02          # (iii) per-step relative loss difference bf16 vs f32
 
 
@@ -69,7 +75,7 @@ def _grads_at_full_size(dt, image, eps, ts, state=None):
     return out, vals
 
 
-def _table(tag, g32, g16, g32b):
+def _table(tag, g32, g16, g32b, trained=False):
     gmax = max(v.norm().item() for v in g32.values())
     rows, bad = [], {}
     for k, ref in g32.items():
@@ -81,10 +87,12 @@ def _table(tag, g32, g16, g32b):
         cos = (got * ref).sum().item() / (got.norm().item() * rn + 1e-300)
         samp = (g32b[k] - ref).norm().item() / rn / (2 ** 0.5)          # sampling noise of ONE batch's gradient
         rows.append((k, rel, cos, samp))
-        last_bn1 = k.startswith("decoder.uplayer5.0.bn1.")
-        if not (rel <= (REL_L2_MAX_BN1_LAST if last_bn1 else REL_L2_MAX) and cos >= (COS_MIN_BN1_LAST if last_bn1 else COS_MIN)):
+        last_bn1 = k.startswith("decoder.uplayer5.0.bn1.") and not trained
+        rmax = REL_L2_MAX_TRAINED if trained else (REL_L2_MAX_BN1_LAST if last_bn1 else REL_L2_MAX)
+        cmin = COS_MIN_TRAINED if trained else (COS_MIN_BN1_LAST if last_bn1 else COS_MIN)
+        if not (rel <= rmax and cos >= cmin):
             bad[k] = ("abs", rel, cos)
-        elif rel > (0.75 if last_bn1 else NOISE_RATIO_MAX) * samp:
+        elif rel > (0.65 if last_bn1 else NOISE_RATIO_MAX) * samp:
             bad[k] = ("vs sampling noise", rel, samp)
     print(f"\nconfig 2, N=5120, {tag}: bf16 vs f32 gradients per tensor (rel-L2, cosine) | sampling noise of the f32 gradient (rel-L2)")
     for k, rel, cos, samp in rows:
@@ -121,7 +129,7 @@ def test_config2_full_size_bf16_gradients_against_f32(oracle):
         assert abs(v16[0] - v32[0]) <= 1e-3 * abs(v32[0]), (tag, v16, v32)          # ELBO within 1e-3 (relative), BASELINE.json
         assert abs(v16[1] - v32[1]) <= 1e-3 * abs(v32[1])
         assert abs(v16[2] - v32[2]) <= 2e-2 * max(abs(v32[2]), 1.0)
-        bad = _table(tag, g32, g16, g32b)
+        bad = _table(tag, g32, g16, g32b, trained=state is not None)
         if bad:
             allbad[tag] = bad
     assert not allbad, allbad

@@ -5,8 +5,8 @@ bench.py only quotes them for the build they were measured on.
   write_bytes = WRITE_SIZE * 1024
 keys: uplayer5.conv2.fwd   the last convT4_stream_kernel (else patch_conv_kernel) dispatch before the tail forward kernel
       (decoder.uplayer5.0.conv2 forward)
-      uplayer5.join_bwd_apply   the apply pass of the last up-block's join backward (tail_apply_mfma_kernel, else the second
-      tail_join_bwd_kernel dispatch of the step)
+      uplayer5.join_bwd   the last up-block's backward in one pass (join_bwd_stream_kernel); builds without it:
+      uplayer5.join_bwd_apply = the apply pass of the join backward (tail_apply_mfma_kernel, else the second tail_join_bwd_kernel dispatch)
       __step__   every dispatch of the last train step (between two Adam kernels)
 usage: python tools/pmc_hbm_csv.py <fetch counter_collection.csv> <write counter_collection.csv> <frames> > profiles/rNN_pmc_hbm.csv"""
 import csv
@@ -41,9 +41,13 @@ def pick(step):
     conv = "convT4_stream_kernel" if any("convT4_stream_kernel" in n for n in names[:j]) else "patch_conv_kernel"
     i = max(k for k in range(j) if conv in names[k])
     out["uplayer5.conv2.fwd"] = step[i][1]
+    jb = [k for k, n in enumerate(names) if "join_bwd_stream_kernel" in n]
     ta = [k for k, n in enumerate(names) if "tail_apply_mfma_kernel" in n]
     tb = [k for k, n in enumerate(names) if "tail_join_bwd_kernel" in n]
-    out["uplayer5.join_bwd_apply"] = step[ta[0] if ta else tb[1]][1]
+    if jb:
+        out["uplayer5.join_bwd"] = step[jb[0]][1]
+    elif ta or len(tb) > 1:
+        out["uplayer5.join_bwd_apply"] = step[ta[0] if ta else tb[1]][1]
     return out
 
 
@@ -52,8 +56,9 @@ def main(fetch_csv, write_csv, frames):
     f = pick(last_step(per_dispatch(fetch_csv, "FETCH_SIZE")))
     w = pick(last_step(per_dispatch(write_csv, "WRITE_SIZE")))
     print("build,frames,key,fetch_bytes,write_bytes")
-    for k in ("uplayer5.conv2.fwd", "uplayer5.join_bwd_apply", "__step__"):
-        print(f"{build},{int(frames)},{k},{2 * f[k] * 1024:.0f},{w[k] * 1024:.0f}")
+    for k in ("uplayer5.conv2.fwd", "uplayer5.join_bwd", "uplayer5.join_bwd_apply", "__step__"):
+        if k in f:
+            print(f"{build},{int(frames)},{k},{2 * f[k] * 1024:.0f},{w[k] * 1024:.0f}")
 
 
 if __name__ == "__main__":
