@@ -11,7 +11,7 @@ namespace mmvae {
 
 // Grid cap of the grid-stride elementwise kernels: 768 = three blocks per CU.  Per kernel it makes no difference (bn_bwd_apply 62 us,
 // affine_join 33 us at 512 .. 2048 blocks), the STEP gains 0.06 ms over 2048 (7.91 vs 7.98 ms, twice on one box; 512: 7.92, 640: 7.96,
-// 896: 8.00): fewer resident blocks leave the weight-gradient kernels of the side stream more of every CU.  MMVAE_ELEM_BLOCKS overrides.
+// 896: 8.00): fewer resident blocks leave the weight-gradient kernels of the side stream more of every CU.
 constexpr int kElemMaxBlocks = 768;
 
 __host__ __device__ inline int block_threads_for(int cvecs) {
@@ -21,7 +21,7 @@ __host__ __device__ inline int block_threads_for(int cvecs) {
 }
 
 static int elem_blocks(long nvec, int threads) {
-  static const int cap = [] { const char* e = getenv("MMVAE_ELEM_BLOCKS"); return e ? atoi(e) : kElemMaxBlocks; }();
+  constexpr int cap = kElemMaxBlocks;
   long b = (nvec + (long)threads * 4 - 1) / ((long)threads * 4);
   if (b < 1) b = 1;
   if (b > cap) b = cap;
@@ -991,8 +991,7 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
 #define MMVAE_LAUNCH(T, OC1, WG) hipLaunchKernelGGL((tail_join_bwd_kernel<T, OC1, APPLY, WG>), dim3(blocks), dim3(256), sm, s, tg, ms, mb, ms1, mb1, \
     (const T*)y0, A0, B0, C0, (T*)dy0, (const T*)y1, A1, B1, C1, (T*)dy1, partials, wpartials)
   if constexpr (APPLY) {
-    static const bool mfma_apply_env = [] { const char* e = getenv("MMVAE_TAIL_APPLY_MFMA"); return !(e && e[0] == '0'); }();
-    if (dt != DT_F32 && OC == 1 && W >= 32 && mfma_apply_env) {
+    if (dt != DT_F32 && OC == 1 && W >= 32) {
       // measured at 5120 frames: 512 blocks 462 us, 640: 499, 704: 460, 768: 443, 896 / 1024: 521, 1280: 506 (five fit a CU) -- whole
       // multiples of the CU count, and no more concurrent read + write streams than the memory system likes
       const int nb = ntiles < 768 ? ntiles : 768;
@@ -1005,8 +1004,7 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
     }
   }
   if constexpr (!APPLY) {
-    static const bool mfma_env = [] { const char* e = getenv("MMVAE_TAIL_REDUCE_MFMA"); return !(e && e[0] == '0'); }();
-    if (wpartials && dt != DT_F32 && OC == 1 && W >= 32 && mfma_env) {
+    if (wpartials && dt != DT_F32 && OC == 1 && W >= 32) {
       const int nb = ntiles < 1024 ? ntiles : 1024;                  // four blocks per CU (114 VGPRs): one resident round (314 us; 768: 345, 512: 411)
       const int tf = ((pt / W + 2) * (W + 2) + 3) & ~3;
       const size_t lds = ((size_t)4 * (tf + 8) + 4 * 512 + 192 + 576) * sizeof(float);

@@ -188,9 +188,8 @@ int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const 
   a.stats = stats; a.stats_sc = stats_sc; a.N = N; a.Ho = Ho; a.Hi = stride * Ho;
   a.HS = Ho % 8 == 0 ? 8 : Ho;
   a.nunits = N * (Ho / a.HS);
-  // blocks: measured per kernel at 5120 frames (developer override: MMVAE_GX_CONV3): stride 1 62 us at 512, 55 at 768 / 1024; stride 2 flat
-  static const int gx0 = [] { const char* e = getenv("MMVAE_GX_CONV3"); return e ? atoi(e) : 0; }();
-  int gx = gx0 > 0 ? gx0 : (stride == 1 ? 768 : 512);
+  // blocks: measured per kernel at 5120 frames : stride 1 62 us at 512, 55 at 768 / 1024; stride 2 flat
+  int gx = stride == 1 ? 768 : 512;
   while (gx > 8 && (long)gx * 4 > a.nunits) gx -= 8;
   const bool pro = pro_scale != nullptr;
   const size_t lds = 2048 + 4 * (size_t)((3 + stride) * (stride * 16 + 2) * 64);
@@ -478,10 +477,9 @@ int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const
   ConvT4StreamArgs a; memset(&a, 0, sizeof(a));
   a.x = x; a.w = w_up; a.y = y; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu; a.stats = stats;
   a.N = N; a.Hi = Hin; a.HS = Hin % 8 == 0 ? 8 : Hin; a.nunits = N * (Hin / a.HS);
-  // blocks (MMVAE_GX_CONVT4 overrides): 32x32 inputs 324 / 293 us (the pair of uplayer5, on two streams) at 768, 308 / 253 at 1024,
+  // blocks : 32x32 inputs 324 / 293 us (the pair of uplayer5, on two streams) at 768, 308 / 253 at 1024,
   // 318 / 306 at 1280; 16x16 inputs 123 us at 768, 130 at 1024
-  static const int gx0 = [] { const char* e = getenv("MMVAE_GX_CONVT4"); return e ? atoi(e) : 0; }();
-  int gx = gx0 > 0 ? gx0 : (Hin == 32 ? 1024 : 768);
+  int gx = Hin == 32 ? 1024 : 768;
   while (gx > 8 && (long)gx * 4 > a.nunits) gx -= 8;
   const bool pro = pro_scale != nullptr;
   const size_t lds = 1024 + 4 * (size_t)(4 * (Hin + 2) * 32 + 2 * Hin * 32);
@@ -503,9 +501,8 @@ int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float*
   TailFwdStreamArgs a; memset(&a, 0, sizeof(a));
   a.y2 = y2; a.ys = ys; a.s2 = s2; a.b2 = b2; a.ss = ss; a.bs = bs; a.w = w; a.bias = bias; a.r_raw = r_raw; a.stats = stats;
   a.N = N; a.H = H; a.HS = 16; a.nunits = N * (H / a.HS);
-  // blocks (MMVAE_GX_TAILFWD overrides): 485 us at 256, 353 at 512, 333 at 768, 346 at 1024, 379 at 1280
-  static const int gx0 = [] { const char* e = getenv("MMVAE_GX_TAILFWD"); return e ? atoi(e) : 768; }();
-  int gx = gx0;                                              // rows of `stats` <= N: the entry point's contract is an [N][2] buffer
+  // blocks : 485 us at 256, 353 at 512, 333 at 768, 346 at 1024, 379 at 1280
+  int gx = 768;                                              // rows of `stats` <= N: the entry point's contract is an [N][2] buffer
   while (gx > 1 && (long)gx * 4 > a.nunits) gx -= gx > 8 ? 8 : 1;
   const size_t lds = 64 + 4 * (size_t)(4 * 66 * 32);
   hipLaunchKernelGGL(tail_fwd_stream_kernel, dim3(gx), dim3(256), lds, s, a);

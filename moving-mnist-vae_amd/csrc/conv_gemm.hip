@@ -390,8 +390,7 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   }
   // tile size: 128 q-pixels, or 256 / 512 (whole rows, power-of-two width >= 16) for the 16- and 32-channel layers:
   // bigger tiles amortise barriers, tile decode and the patch halo
-  static const int sub_env = [] { const char* e = getenv("MMVAE_PATCH_SUB"); return e ? atoi(e) : 0; }();
-  static const int uni_env = [] { const char* e = getenv("MMVAE_PATCH_UNI"); return e ? atoi(e) : 1; }();
+  constexpr int sub_env = 0, uni_env = 1;
   int max_sub = ct16 == 1 ? (a.x_planar ? 4 : 2) : 1;       // measured per layer class (tools/sweep_env.sh MMVAE_PATCH_SUB)
   if (sub_env > 0) { const int inst = ct16 == 1 ? 4 : (ct16 == 2 ? 2 : 1); max_sub = sub_env < inst ? sub_env : inst; }
   // uniform geometry (whole rows, power-of-two width >= 16, every (ph, pw) phase present and full-size): LDS epilogue
@@ -532,7 +531,7 @@ bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, i
   return deep2_lds_for(dt, Cin, Cout, hw, Hi * Wi, ntaps_all, npt_min, fp8) <= 150 * 1024;
 }
 static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
-  static const int npt_env = [] { const char* e = getenv("MMVAE_DEEP2_NPT"); return e ? atoi(e) : 0; }();
+  constexpr int npt_env = 0;
   if (a.x_planar || a.y_planes || a.x2) return 0;
   if (a.fp8 && (!a.wfrag || a.accumulate || dt != DT_BF16 || out_dt != DT_BF16)) return 0;
   int Hq = 0, Wq = 0, ntaps_all = 0;
@@ -558,7 +557,7 @@ static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   }
   for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
   for (b.cpt_log2 = 0; (1 << b.cpt_log2) < cpt; ++b.cpt_log2) {}
-  static const int nw_env = [] { const char* e = getenv("MMVAE_DEEP2_NW"); return e ? atoi(e) : 0; }();
+  constexpr int nw_env = 0;
   b.nw = a.Cout / 32 < 8 ? a.Cout / 32 : 8;
   if (nw_env && nw_env <= b.nw && (a.Cout / 32) % nw_env == 0) b.nw = nw_env;
   if ((64 * b.nw) % (a.Cin / VE) != 0) return 0;
@@ -640,7 +639,7 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   }
   if (a.x2) {
     // fragment-major weights are read by deep2_conv_kernel only, which takes one source: two launches then
-    static const bool merge = [] { const char* e = getenv("MMVAE_X2_MERGE"); return !(e && e[0] == '0'); }();
+    constexpr bool merge = true;
     int rc = (merge && !conv_force_v1() && !a.wfrag && !a.wfrag2) ? try_patch(dt, out_dt, a, s) : 0;
     if (rc != 0) return rc;
     GatherArgs m = a; m.x2 = nullptr; m.w2 = nullptr; m.Cin2 = 0; m.wfrag2 = 0;
@@ -677,7 +676,7 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   }
   {
     // thin layers: barrier-free streaming kernel (weights in LDS, pixels straight from global memory)
-    static const int g3_maxk = [] { const char* e = getenv("MMVAE_GATHER3_MAXK"); return e ? atoi(e) : 160; }();
+    constexpr int g3_maxk = 160;
     static const int g3_dbg = [] { const char* e = getenv("MMVAE_DBG"); return e ? atoi(e) : 0; }();
     a.dbg = g3_dbg;
     int maxk = 0;
@@ -878,7 +877,7 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   b.nw = 4;
   // deep layers (>= 32x64 channel tiles, 3x3 / 4x4 kernels): one tap per wave, every tap in one block -> the tile is
   // staged once instead of once per tap group
-  static const int nw_env = [] { const char* e = getenv("MMVAE_WGRAD_NW"); return e ? atoi(e) : 1; }();
+  constexpr int nw_env = 1;
   // (only where the 4-wave block needs several tap groups, and not for 64x64 tiles with 16 waves: 128 VGPRs spill)
   if (nw_env && !a.P_planar && !a.G_planar && ta16 >= 2 && tb16 >= 2 && (a.ntaps == 9 || a.ntaps == 16) && b.TG < a.ntaps &&
       !(a.ntaps == 16 && ta16 * tb16 >= 16)) {
@@ -895,22 +894,8 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
     fits = lds <= kV2MaxLds && wgrad2_patch_slots(b, dt, TB) <= (b.nw == 4 ? 16 : 8);
   }
   if (!fits) return 0;
-  // big tiles (16x16 channel tile, >= 4 taps, P width a power of two >= 32): fewer, larger tiles amortise the per-tile
-  // latency of the thin 64x64 / 32x32 layers
-  static const int big_env = [] { const char* e = getenv("MMVAE_WGRAD_BIG"); return e ? atoi(e) : 1; }();   // measured: no gain (off by default)
-  if (ta16 == 1 && tb16 == 1 && a.ntaps >= 4 && a.Wp >= 32 && (a.Wp & (a.Wp - 1)) == 0 && b.g.TP == 128 && big_env > 1) {
-    for (int sub = big_env > 4 ? 4 : big_env; sub >= 2; sub >>= 1) {
-      Wgrad2Args c = b;
-      if (!make_tile_geom(c.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, 128, sub)) continue;
-      if (c.g.tiles_per_img == 0 || c.g.qr * a.Wp != 128 * sub || a.Hp % c.g.qr != 0) continue;
-      if (c.g.ntiles < 1024 && b.g.ntiles >= 1024) continue;
-      const size_t l2 = wgrad2_lds_bytes(c, dt, TA, TB);
-      if (l2 > 48 * 1024 || wgrad2_patch_slots(c, dt, TB) > 16) continue;
-      b = c; lds = l2; b.big = 1;
-      while ((1 << b.wq_shift) < a.Wp) ++b.wq_shift;
-      break;
-    }
-  }
+  // ("big" 256 / 512-pixel tiles for the 16x16 channel tile were measured in round 2 without a gain; the kernel keeps the template
+  // parameter for the planar-P tail weight gradient, which uses it)
   b.Ca = a.Ca; b.Cb = a.Cb; b.Cb_valid = a.Cb_valid; b.Ca_valid = a.Ca_valid; b.ksz = a.ksz; b.ntaps = a.ntaps;
   b.sA = a.sA; b.sB = a.sB; b.scale = a.scale; b.P_planar = a.P_planar; b.P_planes = a.P_planes; b.G_planar = a.G_planar;
   for (int t = 0; t < 25; ++t) b.tap_off[t] = a.tap_off[t];
@@ -919,8 +904,6 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   const long wsize = (long)a.Ca * a.Cb * a.ntaps;
   // grid: as many persistent blocks as the CUs can hold (LDS-limited), each flushing one partial image tile
   int occ = (int)((160 * 1024) / lds); if (occ > 6) occ = 6; if (occ < 1) occ = 1;
-  static const int occ_env = [] { const char* e = getenv("MMVAE_WGRAD_OCC"); return e ? atoi(e) : 0; }();
-  if (occ_env > 0) occ = occ_env;
   long gx = (256L * occ) / ((long)tiles_ab * zg); if (gx < 1) gx = 1;
   if (!a.scratch) { set_error("wgrad: the partial-image scratch is required (no atomic flush path)"); return MMVAE_ERR_ARG; }
   const bool partial = true;

@@ -201,20 +201,9 @@ int launch_pack(int dt, const PackArgs& a, hipStream_t s);
 void pack_batch_begin();
 int pack_batch_flush(int dt, hipStream_t s);
 
-// ---------------------------------------------------------------- direct stem / tail kernels
-// stem: Conv2d(1 -> Cout<=32 multiple of 8, k5 s2 p2), x [N,H,W] (T) -> y [N,Ho,Wo,Cout] (T)
-int launch_stem_fwd(int dt, const void* x, const float* w /*[Cout][25] f32*/, void* y, int N, int H, int W, int Ho, int Wo,
-                    int Cout, hipStream_t s);
+// ---------------------------------------------------------------- stem im2col
 // im2col of the 1-channel image for the stem weight gradient: col[m][32] (25 taps, 7 zero pads), T
 int launch_stem_im2col(int dt, const void* x, void* col, int N, int H, int W, int Ho, int Wo, hipStream_t s);
-// tail: Conv2d(Cin=16 -> OC<=8, k3 s1 p1, bias), x [N,H,W,16] (T) -> y [N,OC,H,W] f32 (NCHW)
-int launch_tail_fwd(int dt, const void* x, const float* w /*[OC][16][3][3]*/, const float* bias, float* y, int N, int H, int W,
-                    int OC, hipStream_t s);
-// dx[n,h,w,ci] = sum_{oc,kh,kw} dy[n,oc,h+1-kh,w+1-kw] * w[oc][ci][kh][kw]
-int launch_tail_dgrad(int dt, const float* dy, const float* w, void* dx, int N, int H, int W, int OC, hipStream_t s);
-// dW[oc][ci][kh][kw] += sum dy[n,oc,h,w]*x[n,h-1+kh,w-1+kw,ci];  dbias[oc] += sum dy
-int launch_tail_wgrad(int dt, const void* x, const float* dy, float* dW, float* dbias, int N, int H, int W, int OC,
-                      hipStream_t s);
 
 // stem backward in one pass (stem_bwd.hip): BatchNorm sums + the three pixel reductions dW is an affine function of
 bool stem_bwd_fusable(int S);

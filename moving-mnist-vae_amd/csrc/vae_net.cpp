@@ -503,18 +503,10 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   MM_TRY(packs_enc_fwd(params, base, s));
   MM_TRY(pack_batch_flush(dt(), s));
   if (!staged) MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
-  static const bool stem_direct = [] { const char* e = getenv("MMVAE_STEM_DIRECT"); return e && e[0] == '1'; }();
-  if (!stem_direct && cfg.in_ch == 1 && stem_fwd_stream_ok(dt(), S)) {
+  if (cfg.in_ch == 1 && stem_fwd_stream_ok(dt(), S)) {
     const int np = launch_stem_fwd_stream(dt(), base + P.x_t, params + stem.off, base + P.y0, stats, N, S, s);
     MM_TRY(np);
     if (training) MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
-  } else if (stem_direct) {
-    MM_TRY(launch_stem_fwd(dt(), base + P.x_t, params + stem.off, base + P.y0, N, S, S, H1, W1, 32, s));
-    if (training) {
-      const int np = launch_chan_stats_nhwc(dt(), base + P.y0, (long)N * H1 * W1, 32, part, s);
-      MM_TRY(np);
-      MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
-    }
   } else {
     // stem Conv2d(1 -> 32, k5 s2 p2) (model.py:94): the 1-channel image is staged as a zero-padded VE-channel NHWC patch
     // in LDS and runs through the MFMA patch-tile kernel; BatchNorm statistics come out of its epilogue.
@@ -820,7 +812,6 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   }
   // tail conv (+bias) and the output BatchNorm (model.py:193)
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
-  static const bool tail_direct_f = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
   if (tail_fwd_fused()) {
     const Block& B = dec.back();
     if (tail_fwd_stream_ok(dt(), cfg.out_ch, Sd, Sd))
@@ -831,13 +822,6 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
                                 params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
     MM_TRY(np);
     if (training) MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
-  } else if (tail_direct_f) {
-    MM_TRY(launch_tail_fwd(dt(), xin, params + tail.off, params + tail_bias, r_raw, N, Sd, Sd, cfg.out_ch, s));
-    if (training) {
-      np = launch_chan_stats_nchw(r_raw, N, cfg.out_ch, Sd * Sd, part, s);
-      MM_TRY(np);
-      MM_TRY(bn_train(bn_out, params, bnbuf, nbt, base, np, (double)N * Sd * Sd, s));
-    }
   } else {
     // Conv2d(16 -> out_ch, k3 p1, bias): GEMM rows padded to 16 in LDS, epilogue stores the out_ch real rows as NCHW f32
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
@@ -886,9 +870,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                    bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
   else
     MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
-  static const bool tail_wgrad_direct = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_DIRECT"); return e && e[0] == '1'; }();
-  // one output plane: a tiled VALU reduction (launch_tail_wgrad_tile) beats the MFMA wgrad; MMVAE_TAIL_WGRAD_TILE=0 disables it
-  static const bool tail_wgrad_tile_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_TILE"); return !(e && e[0] == '0'); }();
+  // one output plane: a tiled VALU reduction (launch_tail_wgrad_tile) beats the MFMA wgrad
   static const bool tail_fused_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
   static const bool tail_wg_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_IN_REDUCE"); return !(e && e[0] == '0'); }();
   const bool tail_fused = tail_fused_env && !dec.empty() && dec.back().C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
@@ -901,9 +883,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(side_fork(s));
     MM_TRY(launch_tail_wgrad_tile(dt(), base + B.y2, base + B.ys, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2), bnf(B.bs, base, 3),
                                   d_raw, grads + tail.off, wscratch_, N, Sd, Sd, wgrad_stream(s)));
-  } else if (tail_wgrad_direct) {
-    MM_TRY(launch_tail_wgrad(dt(), base + dec.back().out, d_raw, grads + tail.off, nullptr, N, Sd, Sd, cfg.out_ch, s));
-  } else if (tail_wgrad_tile_env && cfg.out_ch == 1 && !dec.empty() && tail_join_fusable(dt(), 1, N, Sd, Sd)) {
+  } else if (cfg.out_ch == 1 && !dec.empty() && tail_join_fusable(dt(), 1, N, Sd, Sd)) {
     MM_TRY(side_fork(s));
     MM_TRY(launch_tail_wgrad_tile(dt(), base + dec.back().out, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, grads + tail.off, wscratch_,
                                   N, Sd, Sd, wgrad_stream(s)));
@@ -918,12 +898,9 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
   }
   int cur = 0;
-  static const bool tail_direct = [] { const char* e = getenv("MMVAE_TAIL_DIRECT"); return e && e[0] == '1'; }();
   // The tail conv's input gradient is not materialised: the last up-block's join backward recomputes it from d_raw
   // (launch_tail_join_bwd_*; MMVAE_TAIL_FUSED=0 restores the separate dgrad kernel).
   if (tail_fused) {
-  } else if (tail_direct) {
-    MM_TRY(launch_tail_dgrad(dt(), d_raw, params + tail.off, base + P.g[cur], N, Sd, Sd, cfg.out_ch, s));
   } else {
     // dx[n,h,w,ci] = sum dy[n,oc,h+1-kh,w+1-kw] * w[oc][ci][kh][kw]: planar f32 source padded to 8 channels in LDS
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));

@@ -52,15 +52,16 @@ def main(trace_csv, seq_path, pmc_path=None, frames=5120):
             for f in fams:
                 shared[f] = fams
     pmc = None
+    pmc_fam = defaultdict(list)              # per family, in dispatch order (the PMC passes are separate runs of the same step)
     if pmc_path:
         pmc = []
         for l in open(pmc_path):
             if l.startswith("#") or not l.strip():
                 continue
-            p = l.split(None, 3)
+            p = l.rstrip().split(None, 3)
             pmc.append((family(p[3]), float(p[1]), float(p[2])))
-        if len(pmc) != len(step):
-            pmc = None
+            pmc_fam[family(p[3])].append((float(p[1]) + float(p[2])) * 1e6)
+    pmc_taken = defaultdict(int)
     fams = defaultdict(lambda: dict(launches=0, ms=0.0, side=0, alg=0.0, hbm=0.0, alg_known=0))
     taken = defaultdict(int)
     single = []
@@ -75,7 +76,9 @@ def main(trace_csv, seq_path, pmc_path=None, frames=5120):
         alg = None
         if lst is not None and taken[key] < len(lst):
             alg = lst[taken[key]]; taken[key] += 1
-        hb = (pmc[i][1] + pmc[i][2]) * 1e6 if (pmc and pmc[i][0] == f) else None
+        hb = None
+        if pmc and pmc_taken[f] < len(pmc_fam[f]):
+            hb = pmc_fam[f][pmc_taken[f]]; pmc_taken[f] += 1
         if alg:
             e["alg"] += alg; e["alg_known"] += 1
         if hb is not None:
