@@ -294,6 +294,25 @@ MMVAE_API int mmvae_upblock_bwd_fused(const float* d_raw, const float* tail_weig
 MMVAE_API int mmvae_conv1x1_bwd_fused(const void* d_a1, const void* y1, const float* s1, const float* b1, const float* A1, const float* B1,
                             const float* C1, const void* xin, const float* sx, const float* bx, const float* w_conv1, float* dw_conv1,
                             void* g_in, int64_t rows, void* scratch, void* stream);
+/* ------------------------------------------------------------------ PixelCNN (reference model.py:212-255)
+ * PixelCNN(in_channels, intermediate_channels, out_channels, layers, "ReLu"):  InstanceNorm2d -> [MaskedConv2d('A' first, then 'B', 7x7 pad 3,
+ * bias) -> InstanceNorm2d -> ReLU] x (layers - 1) -> MaskedConv2d('B').  The masks (model.py:216-220) keep the first 24 ('A') / 25 ('B') taps
+ * of the 7x7 kernel in row-major order: the layers run as convolutions over exactly those taps, so a masked tap's stored weight is never
+ * read and its gradient is left untouched (the reference zeroes the tap before every use, model.py:222).
+ * params / grads: flat f32, per layer weight (out, in, 7, 7) then bias (out) -- the reference's parameter order.  x, d_x: [N,in,S,S] f32;
+ * out, d_out: [N,out,S,S] f32 logits.  in / out channels <= 16, intermediate_channels a multiple of 16 in [16, 256], 2 <= layers <= 16;
+ * dtype f32 or bf16 (storage of the activations between the layers).  mmvae_pixelcnn_bwd needs the workspace of the forward it
+ * differentiates and that forward's x. */
+typedef struct mmvae_pixelcnn mmvae_pixelcnn;
+MMVAE_API int mmvae_pixelcnn_create(mmvae_pixelcnn** out, int in_channels, int intermediate_channels, int out_channels, int layers, int dtype);
+MMVAE_API void mmvae_pixelcnn_destroy(mmvae_pixelcnn* net);
+MMVAE_API int64_t mmvae_pixelcnn_num_params(mmvae_pixelcnn* net);
+MMVAE_API size_t mmvae_pixelcnn_workspace_bytes(mmvae_pixelcnn* net, int N, int S);
+MMVAE_API int mmvae_pixelcnn_fwd(mmvae_pixelcnn* net, int N, int S, const float* x, const float* params, void* workspace, size_t workspace_bytes,
+                       float* out, void* stream);
+MMVAE_API int mmvae_pixelcnn_bwd(mmvae_pixelcnn* net, int N, int S, const float* x, const float* d_out, const float* params, float* grads,
+                       void* workspace, size_t workspace_bytes, float* d_x, void* stream);
+
 /* f32 <-> dtype element conversion (n elements) */
 MMVAE_API int mmvae_convert(int dtype_in, int dtype_out, const void* in, void* out, int64_t n, void* stream);
 

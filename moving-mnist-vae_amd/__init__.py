@@ -4,7 +4,7 @@ The directory name carries a hyphen (it mirrors the upstream repository name), s
 with ``importlib.import_module("moving-mnist-vae_amd")``.  Importing the package does not need
 a GPU; constructing / running the model does, and fails loudly when the HIP library is absent.
 """
-from .main import (MovingMNISTClips, checkpoint_variant, clips_from_npz_array, load_checkpoint, quantise_frames, save_checkpoint, select_model,  # noqa: F401
+from .main import (MovingMNISTClips, checkpoint_variant, clips_from_npz_array, generate, generate_only_pixelcnn, load_checkpoint, quantise_frames, save_checkpoint, select_model,  # noqa: F401
                    train)
 
 

@@ -72,6 +72,12 @@ PROTOTYPES = {
     "mmvae_tail_join_bwd_apply": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_upblock_bwd_fused": (c_int, [P] * 27 + [c_int, P, P]),
     "mmvae_conv1x1_bwd_fused": (c_int, [P] * 13 + [c_int64, P, P]),
+    "mmvae_pixelcnn_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),
+    "mmvae_pixelcnn_destroy": (None, [P]),
+    "mmvae_pixelcnn_num_params": (c_int64, [P]),
+    "mmvae_pixelcnn_workspace_bytes": (c_size_t, [P, c_int, c_int]),
+    "mmvae_pixelcnn_fwd": (c_int, [P, c_int, c_int, P, P, P, c_size_t, P, P]),
+    "mmvae_pixelcnn_bwd": (c_int, [P, c_int, c_int, P, P, P, P, P, c_size_t, P, P]),
     "mmvae_convert": (c_int, [c_int, c_int, P, P, c_int64, P]),
 }
 

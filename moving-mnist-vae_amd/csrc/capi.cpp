@@ -4,6 +4,7 @@
 
 #include "../../include/mmvae.h"
 #include "conv_ops.hpp"
+#include "pixel_net.hpp"
 #include "vae_net.hpp"
 
 namespace mmvae { const char* last_error(); }
@@ -13,6 +14,7 @@ struct mmvae_net { Net* net; };
 struct mmvae_comm { Comm* c; };
 
 static inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+static inline hipStream_t S_(void* s) { return static_cast<hipStream_t>(s); }   // (where a parameter is called S)
 
 extern "C" {
 
@@ -158,6 +160,36 @@ int mmvae_net_set_sync_bn_comm2(mmvae_net* n, mmvae_comm* cm, mmvae_comm* cs) {
   if (!n || (!cm && cs)) { set_error("net_set_sync_bn_comm2: bad argument"); return MMVAE_ERR_ARG; }
   n->net->set_sync_bn_comm(cm ? cm->c : nullptr, cs ? cs->c : nullptr);
   return MMVAE_OK;
+}
+
+// ---- PixelCNN (reference model.py:212-255)
+struct mmvae_pixelcnn { PixelNet* net; };
+int mmvae_pixelcnn_create(mmvae_pixelcnn** out, int in_channels, int intermediate_channels, int out_channels, int layers, int dtype) {
+  if (!out) { set_error("pixelcnn_create: bad argument"); return MMVAE_ERR_ARG; }
+  if (dtype != MMVAE_F32 && dtype != MMVAE_BF16) { set_error("pixelcnn_create: dtype must be f32 or bf16"); return MMVAE_ERR_UNSUPPORTED; }
+  if (in_channels < 1 || in_channels > 16 || out_channels < 1 || out_channels > 16 || layers < 2 || layers > 16 || intermediate_channels < 16 ||
+      intermediate_channels > 256 || intermediate_channels % 16) {
+    set_error("pixelcnn_create: unsupported shape (in %d, intermediate %d, out %d, layers %d): in / out <= 16, intermediate a multiple of 16 in [16, 256], "
+              "2 <= layers <= 16", in_channels, intermediate_channels, out_channels, layers);
+    return MMVAE_ERR_UNSUPPORTED;
+  }
+  mmvae_pixelcnn* h = new (std::nothrow) mmvae_pixelcnn;
+  if (!h) return MMVAE_ERR_ARG;
+  h->net = new PixelNet(in_channels, intermediate_channels, out_channels, layers, dtype == MMVAE_F32 ? DT_F32 : DT_BF16);
+  *out = h;
+  return MMVAE_OK;
+}
+void mmvae_pixelcnn_destroy(mmvae_pixelcnn* h) { if (h) { delete h->net; delete h; } }
+int64_t mmvae_pixelcnn_num_params(mmvae_pixelcnn* h) { return h ? (int64_t)h->net->n_params : -1; }
+size_t mmvae_pixelcnn_workspace_bytes(mmvae_pixelcnn* h, int N, int S) { return (h && N > 0 && S > 0) ? h->net->workspace_bytes(N, S) : 0; }
+int mmvae_pixelcnn_fwd(mmvae_pixelcnn* h, int N, int S, const float* x, const float* params, void* ws, size_t wsb, float* out, void* st) {
+  if (!h || N <= 0 || S <= 0 || !x || !params || !ws || !out) { set_error("pixelcnn_fwd: bad argument"); return MMVAE_ERR_ARG; }
+  return h->net->forward(N, S, x, params, ws, wsb, out, S_(st));
+}
+int mmvae_pixelcnn_bwd(mmvae_pixelcnn* h, int N, int S, const float* x, const float* d_out, const float* params, float* grads, void* ws, size_t wsb,
+                       float* d_x, void* st) {
+  if (!h || N <= 0 || S <= 0 || !x || !d_out || !params || !grads || !ws) { set_error("pixelcnn_bwd: bad argument"); return MMVAE_ERR_ARG; }
+  return h->net->backward(N, S, x, d_out, params, grads, ws, wsb, d_x, S_(st));
 }
 
 // ---- latent / loss

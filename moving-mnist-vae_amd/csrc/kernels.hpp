@@ -302,6 +302,16 @@ int launch_gauss_tail_reduce(const float* raw, const float* target, const float*
 int launch_gauss_tail_apply(const float* raw, const float* target, const float* scale, const float* shift, float sigma, float coef, const float* gscale,
                             const float* A, const float* B, const float* Cc, float* dy, int N, int C, int HW, hipStream_t s);
 
+// ---------------------------------------------------------------- PixelCNN pieces (pixelcnn.hip; reference model.py:227-255)
+// InstanceNorm2d (affine = False, eps 1e-5, instance statistics always) forward / backward fused with the ReLU behind it, and the layout
+// changes between NCHW f32 and NHWC storage type with 16 zero-padded channels.  stats: [N][C][2] = (mean, istd).
+int launch_inorm_planar_fwd(int dt, const float* x, void* xn16, float* stats, int N, int C, int HW, hipStream_t s);
+int launch_inorm_planar_bwd(int dt, const void* g16, const float* x, const float* stats, float* dx, int N, int C, int HW, hipStream_t s);
+int launch_inorm_nhwc_fwd(int dt, const void* h, void* a, float* stats, int N, int C, int HW, int relu, hipStream_t s);
+int launch_inorm_nhwc_bwd(int dt, const void* g, const void* h, const float* stats, void* dh, int N, int C, int HW, int relu, hipStream_t s);
+int launch_nhwc16_to_planar(int dt, const void* o16, float* out, int N, int C, int HW, hipStream_t s);
+int launch_planar_to_nhwc16(int dt, const float* in, void* o16, int N, int C, int HW, hipStream_t s);
+
 // ---------------------------------------------------------------- latent / loss
 // enc = mu + exp(0.5*logvar)*eps (f32 and T copies); kl_partial: -0.5*sum(lv - exp(lv) - mu^2 + 1) (one float, atomically added)
 int launch_rsample_fwd(int dt, const float* mu, const float* logvar, const float* eps, float* enc_f32, void* enc_t, long n,

@@ -112,37 +112,62 @@ def _is_number(text) -> bool:
 
 
 def select_model(args):
-    """Model factory with the reference's name grammar and keyword mapping (main.py:41-147) for the VAE family:
-    ``<normal|categorical>_vae_<kl>_kl_<mmd>_mmd``.  Returns ``(model, model_params)`` with the reference's dict keys.
-    ``pixelcnn_<n>`` and ``*_pixelvae_*`` names raise NotImplementedError (PixelCNN is out of scope)."""
+    """Model factory with the reference's name grammar and keyword mapping (main.py:41-147):
+    ``pixelcnn_<layers>`` | ``<normal|categorical>_<vae|pixelvae>_<kl>_kl_<mmd>_mmd``.  Returns ``(model, model_params)`` with the reference's
+    dict keys."""
     from .model import VAE
     parts = args.model.split("_")
-    if len(parts) == 2:
-        if parts[0] != "pixelcnn" or not _is_number(parts[1]):
+    if len(parts) == 2:                                                         # main.py:57-66
+        if parts[0] != "pixelcnn":
             raise AssertionError("It has to be only pixelcnn_2/4/7")
-        raise NotImplementedError("pixelcnn_<n> models are not built (PixelCNN is out of scope)")
-    if not (len(parts) == 6 and parts[1] in ("vae", "pixelvae") and parts[3] == "kl" and parts[5] == "mmd"):
-        raise AssertionError("model name should be of the format normal_vae_1_kl_10_mmd")
-    if not (_is_number(parts[2]) and _is_number(parts[4])):
-        raise AssertionError("coefficients should be numeric")
-    if parts[1] == "pixelvae":
-        raise NotImplementedError("*_pixelvae_* models are not built (PixelCNN is out of scope)")
-    is_normal = parts[0] == "normal"
-    if is_normal and args.sigma_decoder == 0:                      # main.py:91-93
-        raise AssertionError("sigma_decoder should be non-zero for normal_vae_* models")
-    mp = {"model_name": "VAE", "is_decoder_out_normal": is_normal, "only_pixelcnn": False, "use_pixelcnn": False,
-          "coeff_kl": float(parts[2]), "coeff_mmd": float(parts[4]),
-          "input_channels": args.input_channels, "input_image_size": args.input_image_size,
-          "intermediate_channels": args.intermediate_channels, "z_dimension": args.z_dimension,
-          "sigma_decoder": args.sigma_decoder, "require_rsample": args.require_rsample,
-          "num_pixelcnn_layers": getattr(args, "num_pixelcnn_layers", 4),
-          "pixelcnn_activation": getattr(args, "pixelcnn_activation", "ReLu"), "coeff_nll": args.nll,
-          "pixelcnn_out_channels": 0}
-    # Gaussian decoder: as many channels as the input; categorical: one per quantisation level (main.py:124-132)
-    mp["decoder_out_channels"] = mp["input_channels"] if is_normal else int(args.quantization)
+        if not _is_number(parts[1]):
+            raise AssertionError("The number of layers has to be an int")
+        only_pixelcnn = use_pixelcnn = True
+        args.num_pixelcnn_layers = int(float(parts[1]))
+        mp = {"model_name": "PixelCNN", "is_decoder_out_normal": False, "only_pixelcnn": True, "use_pixelcnn": True, "coeff_kl": 0., "coeff_mmd": 0.}
+    else:                                                                       # main.py:69-87
+        only_pixelcnn = False
+        if not (len(parts) == 6 and "vae" in parts[1]):
+            raise AssertionError("model name should be of the format normal_pixelvae_1_kl_10_mmd")
+        if parts[1] not in ("pixelvae", "vae"):
+            raise AssertionError("model should be vae or pixelvae")
+        if not (_is_number(parts[2]) and _is_number(parts[4])):
+            raise AssertionError("coefficients should be numeric")
+        use_pixelcnn = parts[1] == "pixelvae"
+        is_normal = parts[0] == "normal"
+        mp = {"is_decoder_out_normal": is_normal, "only_pixelcnn": False, "use_pixelcnn": use_pixelcnn,
+              "coeff_kl": float(parts[2]), "coeff_mmd": float(parts[4])}
+        if use_pixelcnn:
+            mp["model_name"] = "PixelVAE"
+            if not is_normal and not (args.decoder_out_channels > args.input_channels):
+                raise AssertionError("decoder_out_channels should be > input_channels when categorical_pixelvae else simply use normal_pixelvae")
+        else:
+            mp["model_name"] = "VAE"
+    # main.py:91-93: normal_vae_* needs sigma_decoder != 0, normal_pixelvae_* needs sigma_decoder == 0
+    if mp["is_decoder_out_normal"] and not (use_pixelcnn == (args.sigma_decoder == 0)):
+        raise AssertionError("sigma_decoder should be 0 when using vae and non-zero when using pixelvae/pixelcnn")
+    if use_pixelcnn:                                                            # main.py:95-100
+        if not getattr(args, "num_pixelcnn_layers", 4) >= 2:
+            raise AssertionError("num of pixelcnn layers should be greater than 2 when using pixelvae/pixelcnn")
+        if getattr(args, "pixelcnn_activation", "ReLu") not in ("ReLu", "ELU"):
+            raise AssertionError("Choose either Relu or ELU")
+    mp.update({"input_channels": args.input_channels, "input_image_size": args.input_image_size,
+               "intermediate_channels": args.intermediate_channels, "z_dimension": args.z_dimension,
+               "sigma_decoder": args.sigma_decoder, "require_rsample": args.require_rsample,
+               "num_pixelcnn_layers": getattr(args, "num_pixelcnn_layers", 4),
+               "pixelcnn_activation": getattr(args, "pixelcnn_activation", "ReLu"), "coeff_nll": args.nll})
+    if use_pixelcnn:                                                            # main.py:114-124
+        mp["pixelcnn_out_channels"] = int(args.quantization)
+        if not only_pixelcnn:
+            mp["decoder_out_channels"] = args.input_channels if mp["is_decoder_out_normal"] else args.decoder_out_channels
+        else:
+            mp["decoder_out_channels"] = 0
+    else:                                                                       # main.py:126-134
+        mp["pixelcnn_out_channels"] = 0
+        mp["decoder_out_channels"] = mp["input_channels"] if mp["is_decoder_out_normal"] else int(args.quantization)
     model = VAE(in_channels=mp["input_channels"], intermediate_channels=mp["intermediate_channels"],
                 decoder_out_channels=mp["decoder_out_channels"], pixelcnn_out_channels=mp["pixelcnn_out_channels"],
-                z_dimension=mp["z_dimension"], pixelcnn=False, only_pixelcnn=False,
+                z_dimension=mp["z_dimension"], pixelcnn=mp["use_pixelcnn"], only_pixelcnn=mp["only_pixelcnn"],
                 pixelcnn_layers=mp["num_pixelcnn_layers"], pixelcnn_activation=mp["pixelcnn_activation"],
                 nll=mp["coeff_nll"], kl=mp["coeff_kl"], mmd=mp["coeff_mmd"], require_rsample=mp["require_rsample"],
                 sigma_decoder=mp["sigma_decoder"], input_image_size=mp["input_image_size"],
@@ -150,6 +175,33 @@ def select_model(args):
     # build-defined extensions ride along in the parameter dict (and from there into the checkpoint)
     mp["compute_dtype"], mp["blocks_per_stage"] = model.compute_dtype, model.blocks_per_stage
     return model, mp
+
+
+@torch.no_grad()
+def generate_only_pixelcnn(sample, model, data_mean, data_std):
+    """main.py:186-192: autoregressive sampling of a PixelCNN-only model, pixel by pixel (S * S forward passes; `sample` is updated in place)."""
+    import torch.nn.functional as F
+    out = None
+    for i in range(model.input_image_size):
+        for j in range(model.input_image_size):
+            out = model.run_pixelcnn(sample)
+            probs = F.softmax(out[:, :, i, j], dim=1)
+            sample[:, :, i, j] = torch.multinomial(probs, 1).float() / data_std                      # (sic: the reference does not subtract the mean here)
+    return out, sample
+
+
+@torch.no_grad()
+def generate(z_image, sample, model, data_mean, data_std):
+    """main.py:195-202: autoregressive sampling of a PixelVAE's PixelCNN conditioned on the decoder image."""
+    import torch.nn.functional as F
+    output_ = None
+    for i in range(model.input_image_size):
+        for j in range(model.input_image_size):
+            concat = torch.cat([z_image, sample], dim=1)
+            output_ = model.run_pixelcnn(concat)
+            probs = F.softmax(output_[:, :, i, j], dim=1)
+            sample[:, :, i, j] = (torch.multinomial(probs, 1).float() - data_mean) / data_std
+    return output_, sample
 
 
 def save_checkpoint(model, optimizer, epoch, directory):

@@ -68,7 +68,7 @@ class _EncoderFn(torch.autograd.Function):
         staged = st_ is not None and st_[0] == x.data_ptr() and st_[1] == x._version and st_[2] == ws.data_ptr() and st_[3] == N
         model._staged = None
         fn = lib().mmvae_encoder_fwd_staged if staged else lib().mmvae_encoder_fwd
-        check(fn(model._h, N, ptr(x), ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
+        check(fn(model._h, N, ptr(x), model._net_ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
                  ptr(mu), ptr(logvar), int(training), _stream()), "mmvae_encoder_fwd")
         ctx.model, ctx.N, ctx.training = model, N, training
         ctx.token = model._stamp("enc", training)
@@ -86,12 +86,12 @@ class _EncoderFn(torch.autograd.Function):
         if model.require_rsample:
             d_logvar = torch.zeros((N, z), device=dev) if d_logvar is None else d_logvar.contiguous().float()
         G = model._grad_target()
-        G[:model._dec_off].zero_()
+        G[model._poff:model._dec_off].zero_()
         ws = model._workspace(N, True)
-        check(lib().mmvae_encoder_bwd(model._h, N, ptr(d_mu), ptr(d_logvar), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), _stream()),
+        check(lib().mmvae_encoder_bwd(model._h, N, ptr(d_mu), ptr(d_logvar), model._net_ptr(model._flat), model._net_ptr(G), ptr(ws), ws.numel(), _stream()),
               "mmvae_encoder_bwd")
         if model._sync is not None:
-            model._sync.bucket_ready(G, 0, model._dec_off)
+            model._sync.bucket_ready(G, 0, model._dec_off)      # (a PixelCNN's gradients sit in front and are complete by now: it ran first)
         return (None, None) + model._grad_views(G, 0)
 
 
@@ -103,7 +103,7 @@ class _DecoderFn(torch.autograd.Function):
         recon = torch.empty((N, model.decoder_out_channels, model._dec_side, model._dec_side), device=encoding.device,
                             dtype=torch.float32)
         ws = model._workspace(N, training)
-        check(lib().mmvae_decoder_fwd(model._h, N, ptr(encoding), ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
+        check(lib().mmvae_decoder_fwd(model._h, N, ptr(encoding), model._net_ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
                                       ptr(recon), int(training), _stream()), "mmvae_decoder_fwd")
         ctx.model, ctx.N, ctx.training = model, N, training
         ctx.token = model._stamp("dec", training)
@@ -136,10 +136,10 @@ class _DecoderFn(torch.autograd.Function):
         check(lib().mmvae_net_defer_join(model._h, int(defer)), "mmvae_net_defer_join")
         if fused_tail:
             _, target, sigma, coef, gscale, _ = tail
-            check(lib().mmvae_decoder_bwd_gauss(model._h, N, ptr(target), float(sigma), float(coef), ptr(gscale), ptr(model._flat), ptr(G), ptr(ws),
+            check(lib().mmvae_decoder_bwd_gauss(model._h, N, ptr(target), float(sigma), float(coef), ptr(gscale), model._net_ptr(model._flat), model._net_ptr(G), ptr(ws),
                                                 ws.numel(), ptr(d_enc), _stream()), "mmvae_decoder_bwd_gauss")
         else:
-            check(lib().mmvae_decoder_bwd(model._h, N, ptr(d_recon), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), ptr(d_enc), _stream()),
+            check(lib().mmvae_decoder_bwd(model._h, N, ptr(d_recon), model._net_ptr(model._flat), model._net_ptr(G), ptr(ws), ws.numel(), ptr(d_enc), _stream()),
                   "mmvae_decoder_bwd")
         if defer:
             h, st = model._h, _stream()
@@ -147,6 +147,42 @@ class _DecoderFn(torch.autograd.Function):
         if model._sync is not None:
             model._sync.bucket_ready(G, model._dec_off, model._n_params, side_of=model if defer else None)
         return (None, d_enc) + model._grad_views(G, 1)
+
+
+class _PixelFn(torch.autograd.Function):
+    """PixelCNN.forward (model.py:248-255) through mmvae_pixelcnn_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        N, S = x.shape[0], x.shape[2]
+        x = x.contiguous().float()
+        with torch.no_grad():
+            model._flat[:model._poff].mul_(model._pix_mask)          # model.py:222: weight.data *= mask in every forward
+        out = torch.empty((N, model.pixelcnn_out_channels, S, S), device=x.device, dtype=torch.float32)
+        ws = model._pixel_workspace(N, S)
+        check(lib().mmvae_pixelcnn_fwd(model._hp, N, S, ptr(x), ptr(model._flat), ptr(ws), ws.numel(), ptr(out), _stream()), "mmvae_pixelcnn_fwd")
+        ctx.model, ctx.N, ctx.S = model, N, S
+        ctx.token = model._stamp("pix", True)
+        ctx.need_dx = bool(ctx.needs_input_grad[1])
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        model, N, S = ctx.model, ctx.N, ctx.S
+        if model._stamps.get(("pix", True)) != ctx.token:
+            raise MmvaeError("the saved activations of this PixelCNN forward were overwritten by a later forward")
+        (x,) = ctx.saved_tensors
+        d_out = d_out.contiguous().float()
+        G = model._grad_target()
+        G[:model._poff].zero_()
+        d_x = torch.empty_like(x) if ctx.need_dx else None
+        ws = model._pixel_workspace(N, S)
+        check(lib().mmvae_pixelcnn_bwd(model._hp, N, S, ptr(x), ptr(d_out), ptr(model._flat), ptr(G), ptr(ws), ws.numel(), ptr(d_x), _stream()),
+              "mmvae_pixelcnn_bwd")
+        tab = [e for e in model._ptable if e[2] < model._poff]
+        chunks = G[:model._poff].split([e[3] for e in tab])
+        return (None, d_x) + tuple(c.view(e[4]) for c, e in zip(chunks, tab))
 
 
 class _StepScalars:
@@ -238,7 +274,7 @@ class _LossFn(torch.autograd.Function):
         st = _stream()
         base = acc.data_ptr()
         recon = recon.contiguous()
-        categorical = model.decoder_out_channels > model.in_channels
+        categorical = model.pixelcnn is not None or model.decoder_out_channels > model.in_channels      # model.py:398
         if mu is not None and logvar is not None:
             mu, logvar = mu.contiguous(), logvar.contiguous()
             check(L.mmvae_kl_fwd(ptr(mu), ptr(logvar), mu.numel(), base + 8, st), "mmvae_kl_fwd")
@@ -307,9 +343,9 @@ class VAE(nn.Module):
         ``blocks_per_stage`` (default 1 = the reference network): residual blocks per encoder / decoder stage of the deeper
         build-defined variant (BASELINE configs[3]; include/mmvae.h: mmvae_net_create_ex)."""
         super().__init__()
-        if pixelcnn or only_pixelcnn:
-            raise NotImplementedError("only the plain conv-VAE path (pixelcnn=False, only_pixelcnn=False) is built; "
-                                      "PixelCNN / PixelVAE models are out of scope (SURVEY.md section 8f)")
+        if (pixelcnn or only_pixelcnn) and pixelcnn_activation != "ReLu":
+            # (the reference accepts "ELU" at the command line but its PixelCNN only knows "ReLu" / "Elu": model.py:243-246 vs main.py:100)
+            raise NotImplementedError("PixelCNN is built with the ReLu activation only")
         self.in_channels = in_channels
         self.z_dimensions = z_dimension
         self.decoder_out_channels = decoder_out_channels
@@ -320,7 +356,6 @@ class VAE(nn.Module):
         self.sigma_decoder = sigma_decoder
         self.input_image_size = input_image_size
         self.only_pixelcnn = only_pixelcnn
-        self.pixelcnn = None
         self.adjust = (64 - input_image_size) // 2 if input_image_size > 32 else (32 - input_image_size) // 2   # model.py:307-310
         dt = compute_dtype or os.environ.get("MMVAE_DTYPE", "bf16")
         if dt not in _DTYPES:
@@ -328,18 +363,34 @@ class VAE(nn.Module):
         self.compute_dtype = {0: "f32", 1: "bf16", 2: "fp8"}[_DTYPES[dt]]
 
         L = lib()
-        h = ctypes.c_void_p()
-        self.blocks_per_stage = int(blocks_per_stage)
-        check(L.mmvae_net_create_ex(ctypes.byref(h), in_channels, z_dimension, decoder_out_channels, input_image_size,
-                                    int(bool(require_rsample)), _DTYPES[dt], self.blocks_per_stage), "mmvae_net_create_ex")
-        self.__dict__["_h"] = h
-        n_params, n_bnf, dec_off = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
-        n_bni, dec_side = ctypes.c_int32(), ctypes.c_int32()
-        check(L.mmvae_net_sizes(h, ctypes.byref(n_params), ctypes.byref(n_bnf), ctypes.byref(n_bni), ctypes.byref(dec_off),
-                                ctypes.byref(dec_side)), "mmvae_net_sizes")
         d = self.__dict__
-        d["_n_params"], d["_n_bnf"], d["_n_bni"] = n_params.value, n_bnf.value, n_bni.value
-        d["_dec_off"], d["_dec_side"] = dec_off.value, dec_side.value
+        self.blocks_per_stage = int(blocks_per_stage)
+        d["_ptable"], d["_btable"] = [], []
+        # ---- PixelCNN first: the reference registers it before the encoder / decoder (model.py:283-300), so its parameters lead the
+        # parameter list and the state_dict
+        d["_hp"], d["_poff"], d["_pix_ws"] = None, 0, None
+        pix_tables = None
+        if only_pixelcnn or pixelcnn:
+            pix_in = in_channels if only_pixelcnn else decoder_out_channels + in_channels                      # model.py:288,312
+            hp = ctypes.c_void_p()
+            check(L.mmvae_pixelcnn_create(ctypes.byref(hp), pix_in, intermediate_channels, pixelcnn_out_channels, pixelcnn_layers,
+                                          1 if _DTYPES[dt] != 0 else 0), "mmvae_pixelcnn_create")
+            d["_hp"] = hp
+            d["_poff"] = int(L.mmvae_pixelcnn_num_params(hp))
+            pix_tables = (pix_in, intermediate_channels, pixelcnn_out_channels, pixelcnn_layers)
+        # ---- encoder / decoder
+        d["_h"] = None
+        n_params, n_bnf, dec_off = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        n_bni, dec_side = ctypes.c_int32(0), ctypes.c_int32(0)
+        if not only_pixelcnn:
+            h = ctypes.c_void_p()
+            check(L.mmvae_net_create_ex(ctypes.byref(h), in_channels, z_dimension, decoder_out_channels, input_image_size,
+                                        int(bool(require_rsample)), _DTYPES[dt], self.blocks_per_stage), "mmvae_net_create_ex")
+            d["_h"] = h
+            check(L.mmvae_net_sizes(h, ctypes.byref(n_params), ctypes.byref(n_bnf), ctypes.byref(n_bni), ctypes.byref(dec_off),
+                                    ctypes.byref(dec_side)), "mmvae_net_sizes")
+        d["_n_params"], d["_n_bnf"], d["_n_bni"] = self._poff + n_params.value, n_bnf.value, n_bni.value
+        d["_dec_off"], d["_dec_side"] = self._poff + dec_off.value, dec_side.value          # absolute: first decoder parameter of the flat buffer
         d["_flat"] = torch.zeros(self._n_params, dtype=torch.float32)
         d["_bnf"] = torch.zeros(self._n_bnf, dtype=torch.float32)
         d["_bni"] = torch.zeros(self._n_bni, dtype=torch.int64)
@@ -358,8 +409,12 @@ class VAE(nn.Module):
         d["fuse_loss_tail"] = os.environ.get("MMVAE_FUSE_LOSS_TAIL", "1") != "0"
         d["injected_eps"] = None           # parity tests: noise for rsample / loss instead of torch.randn
         d["injected_true_samples"] = None
-        d["_ptable"], d["_btable"] = [], []
-        self._build_tree(L)
+        if pix_tables is not None:
+            self._build_pixel_tree(*pix_tables)
+        else:
+            self.pixelcnn = None
+        if self._h is not None:
+            self._build_tree(L)
         self._reset_parameters()
 
     # ---- construction helpers
@@ -383,18 +438,50 @@ class VAE(nn.Module):
                     node.add_module(comp, _Scope(self, role))
                 node = node._modules[comp]
             if kind.value == 0:
-                p = nn.Parameter(self._flat[off.value:off.value + numel].view(shp))
+                o = self._poff + off.value
+                p = nn.Parameter(self._flat[o:o + numel].view(shp))
                 p._mmvae_owner = weakref.ref(self)
                 node.register_parameter(parts[-1], p)
-                self._ptable.append((name, p, off.value, numel, shp))
+                self._ptable.append((name, p, o, numel, shp))
             elif kind.value == 1:
                 node.register_buffer(parts[-1], self._bnf[off.value:off.value + numel].view(shp))
                 self._btable.append((node, parts[-1], 1, off.value, numel, shp))
             else:
                 node.register_buffer(parts[-1], self._bni[off.value:off.value + 1].view(()))
                 self._btable.append((node, parts[-1], 2, off.value, 1, ()))
-        self.__dict__["_enc_params"] = [p for (_, p, o, _, _) in self._ptable if o < self._dec_off]
+        self.__dict__["_enc_params"] = [p for (_, p, o, _, _) in self._ptable if self._poff <= o < self._dec_off]
         self.__dict__["_dec_params"] = [p for (_, p, o, _, _) in self._ptable if o >= self._dec_off]
+
+    def _build_pixel_tree(self, pix_in, mid, pix_out, layers):
+        """pixelcnn.layers.<i>.{weight, bias, mask}: the reference's names and order (model.py:234-241; `mask` is a registered buffer, :216)."""
+        top = _Scope(self, None)
+        self.add_module("pixelcnn", top)
+        lay = _Scope(self, None)
+        top.add_module("layers", lay)
+        off = 0
+        masks = []
+        for i in range(layers):
+            cin = pix_in if i == 0 else mid
+            cout = pix_out if i == layers - 1 else mid
+            node = _Scope(self, None)
+            lay.add_module(str(i), node)
+            for leaf, shp in (("weight", (cout, cin, 7, 7)), ("bias", (cout,))):
+                n = 1
+                for v in shp:
+                    n *= v
+                p = nn.Parameter(self._flat[off:off + n].view(shp))
+                p._mmvae_owner = weakref.ref(self)
+                node.register_parameter(leaf, p)
+                self._ptable.append((f"pixelcnn.layers.{i}.{leaf}", p, off, n, shp))
+                off += n
+            m = torch.ones(cout, cin, 7, 7)
+            m[:, :, 3, 3 + (0 if i == 0 else 1):] = 0                  # type 'A' first, 'B' afterwards (model.py:216-220, :234-239)
+            m[:, :, 4:] = 0
+            node.register_buffer("mask", m)
+            masks += [m.reshape(-1), torch.ones(cout)]
+        assert off == self._poff
+        self.__dict__["_pix_mask"] = torch.cat(masks)                     # multiplies the PixelCNN's flat parameter region (biases: ones)
+        self.__dict__["_pix_params"] = [e[1] for e in self._ptable]
 
     @torch.no_grad()
     def _reset_parameters(self):
@@ -407,6 +494,16 @@ class VAE(nn.Module):
         def conv(name):
             nn.init.kaiming_uniform_(byname[name], a=math.sqrt(5))
 
+        # PixelCNN first (constructed first, model.py:283-300): nn.Conv2d.reset_parameters per layer -- weight, then bias
+        i = 0
+        while f"pixelcnn.layers.{i}.weight" in byname:
+            w = byname[f"pixelcnn.layers.{i}.weight"]
+            conv(f"pixelcnn.layers.{i}.weight")
+            bound = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
+            nn.init.uniform_(byname[f"pixelcnn.layers.{i}.bias"], -bound, bound)
+            i += 1
+        if self._h is None:
+            return
         conv("encoder.conv1.weight")
         for i in range(1, 5):
             j = 0
@@ -436,7 +533,7 @@ class VAE(nn.Module):
         bound = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
         nn.init.uniform_(byname["decoder.conv2.bias"], -bound, bound)
         for (name, p, _, _, shp) in self._ptable:
-            if len(shp) == 1 and name != "decoder.conv2.bias":
+            if len(shp) == 1 and name != "decoder.conv2.bias" and not name.startswith("pixelcnn."):
                 p.fill_(1.0 if name.endswith(".weight") else 0.0)
         for (node, leaf, k, _, _, _) in self._btable:
             b = node._buffers[leaf]
@@ -473,6 +570,9 @@ class VAE(nn.Module):
         d["_flat"], d["_bnf"], d["_bni"] = flat, bnf, bni
         d["_G"] = [None, None]
         d["_ws"] = {True: None, False: None}
+        d["_pix_ws"] = None
+        if self._hp is not None:
+            d["_pix_mask"] = self._pix_mask.to(dev)
 
     def _ensure_flat(self):
         first, last = self._ptable[0], self._ptable[-1]
@@ -482,6 +582,18 @@ class VAE(nn.Module):
         if not self._flat.is_cuda:
             raise MmvaeError("the HIP VAE only runs on a GPU: call model.to('cuda') first (there is no CPU fallback; "
                              "the CPU restatement under oracle/ is test infrastructure)")
+
+    def _net_ptr(self, flat_like):
+        """Device address of the encoder / decoder's region of a flat parameter-shaped buffer (behind the PixelCNN's, if any)."""
+        return flat_like.data_ptr() + 4 * self._poff
+
+    def _pixel_workspace(self, N, S):
+        need = lib().mmvae_pixelcnn_workspace_bytes(self._hp, int(N), int(S))
+        ws = self._pix_ws
+        if ws is None or ws.numel() < need or ws.device != self._flat.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=self._flat.device)
+            self.__dict__["_pix_ws"] = ws
+        return ws
 
     def _workspace(self, N, training):
         need = lib().mmvae_net_workspace_bytes(self._h, int(N))
@@ -528,7 +640,7 @@ class VAE(nn.Module):
         return self._G[idx]
 
     def _grad_views(self, G, part):
-        tab = [e for e in self._ptable if (e[2] < self._dec_off) == (part == 0)]
+        tab = [e for e in self._ptable if ((self._poff <= e[2] < self._dec_off) if part == 0 else e[2] >= self._dec_off)]
         lo = tab[0][2]
         hi = tab[-1][2] + tab[-1][3]
         chunks = G[lo:hi].split([e[3] for e in tab])
@@ -561,20 +673,41 @@ class VAE(nn.Module):
             out = out[:, :, self.adjust:-self.adjust, self.adjust:-self.adjust]
         return out
 
+    def run_pixelcnn(self, concat):                            # model.py:350-351
+        if self._hp is None:
+            raise MmvaeError("this model has no PixelCNN")
+        self._ensure_flat()
+        x = concat.contiguous().float()
+        if x.dim() != 4 or x.shape[2] != x.shape[3]:
+            raise ValueError(f"expected a square (N, C, S, S) input, got {tuple(x.shape)}")
+        return _PixelFn.apply(self, x, *self._pix_params_live())
+
+    def _pix_params_live(self):
+        return [e[1] for e in self._ptable if e[2] < self._poff]
+
     def forward(self, x, sample=None):
-        """model.py:316-342 (pixelcnn=None): returns (mu, logvar, encoding, reconstruction)."""
+        """model.py:316-342: returns (mu, logvar, encoding, reconstruction).  With a PixelCNN the reconstruction is its output on
+        concat([decoder_output, x]) in train mode / concat([decoder_output, sample]) in eval mode (:331-336); only_pixelcnn: on x itself."""
+        if self.only_pixelcnn:
+            return None, None, None, self.run_pixelcnn(x)                                   # :339-340
         mu, logvar = self._encode(x)
         encoding = self._rsample(mu, logvar) if self.require_rsample else mu
-        return mu, logvar, encoding, self._decode(encoding)
+        decoder_output = self._decode(encoding)
+        if self._hp is None:
+            return mu, logvar, encoding, decoder_output
+        other = x if self.training else sample
+        if other is None:
+            raise ValueError("a PixelVAE in eval mode needs `sample` (model.py:334-335)")
+        return mu, logvar, encoding, self.run_pixelcnn(torch.cat([decoder_output, other.to(decoder_output.dtype)], dim=1))
 
     def get_z_image(self, encoding):                           # model.py:344-348
         return self._decode(encoding)
 
     def get_reconstruction(self, encoding, sample=None):       # model.py:353-362
-        return self._decode(encoding)
-
-    def run_pixelcnn(self, concat):                            # model.py:350-351
-        raise NotImplementedError("PixelCNN is out of scope")
+        decoder_output = self._decode(encoding)
+        if self._hp is None:
+            return decoder_output
+        return self.run_pixelcnn(torch.cat([decoder_output, sample.to(decoder_output.dtype)], dim=1))
 
     def kl_divergence(self, encoding_mu, encoding_logvar):     # model.py:364-365
         acc = torch.zeros(1, dtype=torch.float64, device=encoding_mu.device)
@@ -604,7 +737,7 @@ class VAE(nn.Module):
         does not wait for the forward pass before it enqueues the backward pass."""
         N = target.shape[0]
         dev = reconstruction.device
-        categorical = self.decoder_out_channels > self.in_channels
+        categorical = self.pixelcnn is not None or self.decoder_out_channels > self.in_channels          # model.py:398
         ts = None
         enc2 = None
         if encoding is not None:
@@ -652,17 +785,29 @@ class VAE(nn.Module):
         return image, target
 
     def __repr__(self):
-        """The reference's description text (model.py:408-439) for the built configurations (pixelcnn is None)."""
+        """The reference's description text (model.py:408-439)."""
         size = str(self.input_image_size) + "x" + str(self.input_image_size) + "x"
-        rsample_text = " Where Z is rsampled from a Normal Distribution." if self.require_rsample else ""
-        string = ("We are using an encoder which takes input of " + size + str(self.in_channels) + " and encodes into " +
-                  str(self.z_dimensions) + " dimensional latent space." + rsample_text +
-                  " \nIt is then pushed into a decoder which outputs an image of dimension " + size +
-                  str(self.decoder_out_channels) + ".\n")
-        if self.decoder_out_channels == self.in_channels:
-            string += "We assume p(x/z) follows a normal distribution with mean x_recon and sigma " + str(self.sigma_decoder) + ".\n"
+        string = ""
+        pixelcnn_input = size
+        if self.only_pixelcnn:
+            pixelcnn_used = "by itself"
+            pixelcnn_input += str(self.in_channels)
         else:
-            string += "We assume p(x/z) follows a categorical distribution. \n"
+            pixelcnn_used = "in the decoder"
+            pixelcnn_input += str(self.in_channels + self.decoder_out_channels)
+            rsample_text = " Where Z is rsampled from a Normal Distribution." if self.require_rsample else ""
+            string += ("We are using an encoder which takes input of " + size + str(self.in_channels) + " and encodes into " +
+                       str(self.z_dimensions) + " dimensional latent space." + rsample_text +
+                       " \nIt is then pushed into a decoder which outputs an image of dimension " + size +
+                       str(self.decoder_out_channels) + ".\n")
+        if self.pixelcnn is None:
+            if self.decoder_out_channels == self.in_channels:
+                string += "We assume p(x/z) follows a normal distribution with mean x_recon and sigma " + str(self.sigma_decoder) + ".\n"
+            else:
+                string += "We assume p(x/z) follows a categorical distribution. \n"
+        else:
+            string += ("We are using PixelCNN " + pixelcnn_used + " which takes an input of " + pixelcnn_input + " dimension goes through " +
+                       str(self.num_pixelcnn_layers) + " layers and outputs a " + size + str(self.pixelcnn_out_channels) + " dimensions image")
         return string
 
     def extra_repr(self):
@@ -673,6 +818,9 @@ class VAE(nn.Module):
             h = self.__dict__.get("_h")
             if h:
                 lib().mmvae_net_destroy(h)
+            hp = self.__dict__.get("_hp")
+            if hp:
+                lib().mmvae_pixelcnn_destroy(hp)
         except Exception:
             pass
 

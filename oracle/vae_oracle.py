@@ -156,6 +156,9 @@ def filled_state(spec, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
             t = torch.rand(shape, generator=g) + 0.5
         elif kind == "bn_nbt":
             t = torch.tensor(0, dtype=torch.long)
+        elif kind == "mask":
+            # "pixelcnn.layers.<i>.mask": type A for the first layer, B for the others (model.py:234-239)
+            t = pixelcnn_mask("A" if name.split(".")[-2] == "0" else "B", shape[0], shape[1])
         else:  # pragma: no cover
             raise ValueError(kind)
         sd[name] = t
@@ -291,6 +294,52 @@ def vae_forward(sd, x: torch.Tensor, eps: Optional[torch.Tensor], input_image_si
     recon = crop(decoder_forward(sd, encoding, input_image_size, training, taps),
                  adjust_for(input_image_size))
     return mu, logvar, encoding, recon
+
+
+# --------------------------------------------------------------------------
+# PixelCNN / PixelVAE: MaskedConv2d model.py:212-224, PixelCNN :227-255, the concat of VAE.forward :331-336
+# --------------------------------------------------------------------------
+IN_EPS = 1e-5        # nn.InstanceNorm2d default (affine=False, no running statistics: instance statistics in train AND eval mode)
+
+
+def pixelcnn_spec(in_channels: int, intermediate_channels: int, out_channels: int, layers: int,
+                  prefix: str = "pixelcnn.") -> List[Tuple[str, Tuple[int, ...], str]]:
+    """state_dict entries of PixelCNN in the reference's order (model.py:234-241): per layer weight, bias and the registered
+    `mask` buffer (:216); the InstanceNorm2d modules have neither parameters nor buffers."""
+    s: List[Tuple[str, Tuple[int, ...], str]] = []
+    for i in range(layers):
+        cin = in_channels if i == 0 else intermediate_channels
+        cout = out_channels if i == layers - 1 else intermediate_channels
+        p = f"{prefix}layers.{i}."
+        s.append((p + "weight", (cout, cin, 7, 7), "conv"))
+        s.append((p + "bias", (cout,), "bias"))
+        s.append((p + "mask", (cout, cin, 7, 7), "mask"))
+    return s
+
+
+def pixelcnn_mask(mask_type: str, cout: int, cin: int) -> torch.Tensor:
+    """model.py:216-220: ones; the centre row from the centre (type A) / right of the centre (type B) on and every row below are zero."""
+    m = torch.ones(cout, cin, 7, 7)
+    m[:, :, 3, 3 + (mask_type == "B"):] = 0
+    m[:, :, 4:] = 0
+    return m
+
+
+def instance_norm(x: torch.Tensor) -> torch.Tensor:
+    return F.instance_norm(x, eps=IN_EPS)
+
+
+def pixelcnn_forward(sd, x: torch.Tensor, layers: int, prefix: str = "pixelcnn.") -> torch.Tensor:
+    """PixelCNN.forward, model.py:248-255 with activation "ReLu": x = IN(x); (masked conv 7x7 pad 3 -> IN -> ReLU) x (layers - 1);
+    masked conv.  The reference multiplies weight.data by the mask in place in every forward (:222-223); the functional form uses the
+    masked weight (same values; the gradient w.r.t. the stored weight at masked taps differs: see tests)."""
+    x = instance_norm(x)                                                          # :249
+    for i in range(layers):
+        w = sd[f"{prefix}layers.{i}.weight"] * sd[f"{prefix}layers.{i}.mask"]     # :222
+        x = F.conv2d(x, w, sd[f"{prefix}layers.{i}.bias"], stride=1, padding=3)   # :223
+        if i < layers - 1:
+            x = F.relu(instance_norm(x))                                          # :252-253
+    return x
 
 
 def get_reconstruction(sd, encoding: torch.Tensor, input_image_size: int, training: bool = False):

@@ -53,7 +53,9 @@ def test_unsupported_configurations_fail_loudly(pkg):
     M = importlib.import_module("moving-mnist-vae_amd.model")
     L = importlib.import_module("moving-mnist-vae_amd._lib")
     with pytest.raises(NotImplementedError):
-        M.VAE(1, 32)                                  # reference default: pixelcnn=True
+        M.VAE(1, 32, pixelcnn_activation="Elu")       # PixelCNN: ReLu only (the reference's ELU branch is unreachable from its CLI, main.py:100)
+    with pytest.raises(L.MmvaeError):
+        M.VAE(1, 24)                                  # PixelCNN intermediate_channels not a multiple of 16
     with pytest.raises(L.MmvaeError):
         M.VAE(3, 32, 1, 2, 32, False, False)          # in_channels != 1
     with pytest.raises(L.MmvaeError):

@@ -28,10 +28,18 @@ def test_select_model_name_grammar(pkg):
         pkg.select_model(_args("normal_vae_x_kl_0_mmd"))
     with pytest.raises(AssertionError):
         pkg.select_model(_args("vae"))
-    with pytest.raises(NotImplementedError):
-        pkg.select_model(_args("pixelcnn_4"))
-    with pytest.raises(NotImplementedError):
-        pkg.select_model(_args("categorical_pixelvae_1_kl_0_mmd", sigma_decoder=0.0))
+    m, mp = pkg.select_model(_args("pixelcnn_4"))                                # main.py:57-66
+    assert mp["model_name"] == "PixelCNN" and m.only_pixelcnn and m.pixelcnn is not None and m.num_pixelcnn_layers == 4
+    assert mp["decoder_out_channels"] == 0 and mp["pixelcnn_out_channels"] == 2 and not hasattr(m, "encoder")
+    m, mp = pkg.select_model(_args("categorical_pixelvae_1_kl_0_mmd", sigma_decoder=0.0))
+    assert mp["model_name"] == "PixelVAE" and m.pixelcnn is not None and m.decoder_out_channels == 2 and m.pixelcnn_out_channels == 2
+    assert [k for k in m.state_dict()][:3] == ["pixelcnn.layers.0.weight", "pixelcnn.layers.0.bias", "pixelcnn.layers.0.mask"]
+    m, mp = pkg.select_model(_args("normal_pixelvae_1_kl_0_mmd", sigma_decoder=0.0))
+    assert m.decoder_out_channels == 1 and tuple(m.state_dict()["pixelcnn.layers.0.weight"].shape) == (32, 2, 7, 7)
+    with pytest.raises(AssertionError):
+        pkg.select_model(_args("normal_pixelvae_1_kl_0_mmd", sigma_decoder=0.1))  # main.py:91-93
+    with pytest.raises(AssertionError):
+        pkg.select_model(_args("pixelcnn_x"))
 
 
 def test_checkpoint_layout_roundtrips_with_the_oracle_shell(pkg, oracle, tmp_path):
