@@ -28,7 +28,7 @@ int mmvae_net_create_ex(mmvae_net** out, int in_channels, int z, int out_channel
                         int blocks_per_stage) {
   if (!out) return MMVAE_ERR_ARG;
   if (blocks_per_stage < 1 || blocks_per_stage > 4) { set_error("blocks_per_stage=%d unsupported (1..4)", blocks_per_stage); return MMVAE_ERR_UNSUPPORTED; }
-  if (in_channels != 1) { set_error("in_channels=%d unsupported (the hot path is the 1-channel Moving-MNIST VAE)", in_channels); return MMVAE_ERR_UNSUPPORTED; }
+  if (in_channels < 1 || in_channels > 4) { set_error("in_channels=%d unsupported (1..4; the benchmarked path is the 1-channel Moving-MNIST VAE)", in_channels); return MMVAE_ERR_UNSUPPORTED; }
   if (z <= 0 || z % 8) { set_error("z_dimension=%d must be a positive multiple of 8", z); return MMVAE_ERR_UNSUPPORTED; }
   if (!(out_channels == 1 || out_channels == 2 || out_channels == 3 || out_channels == 4 || out_channels == 8)) {
     set_error("decoder_out_channels=%d unsupported (1,2,3,4,8)", out_channels); return MMVAE_ERR_UNSUPPORTED; }

@@ -311,6 +311,7 @@ int launch_inorm_nhwc_fwd(int dt, const void* h, void* a, float* stats, int N, i
 int launch_inorm_nhwc_bwd(int dt, const void* g, const void* h, const float* stats, void* dh, int N, int C, int HW, int relu, hipStream_t s);
 int launch_nhwc16_to_planar(int dt, const void* o16, float* out, int N, int C, int HW, hipStream_t s);
 int launch_planar_to_nhwc16(int dt, const float* in, void* o16, int N, int C, int HW, hipStream_t s);
+int launch_planar_to_nhwc16(int dt, const void* in, int in_dt, void* o16, int N, int C, int HW, hipStream_t s);
 
 // ---------------------------------------------------------------- latent / loss
 // enc = mu + exp(0.5*logvar)*eps (f32 and T copies); kl_partial: -0.5*sum(lv - exp(lv) - mu^2 + 1) (one float, atomically added)

@@ -205,14 +205,14 @@ __global__ void nhwc16_to_planar_kernel(const T* __restrict__ o, float* __restri
     for (int c = 0; c < C; ++c) out[(n * C + c) * HW + p] = Elem<T>::load(o + i * 16 + c);
   }
 }
-template <typename T>
-__global__ void planar_to_nhwc16_kernel(const float* __restrict__ in, T* __restrict__ o, long npix, int C, int HW) {
+template <typename T, typename TI>
+__global__ void planar_to_nhwc16_kernel(const TI* __restrict__ in, T* __restrict__ o, long npix, int C, int HW) {
   constexpr int VE = Elem<T>::kVec;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
     const long n = i / HW, p = i - n * HW;
     float f[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) f[c] = c < C ? in[(n * C + c) * HW + p] : 0.f;
+    for (int c = 0; c < 16; ++c) f[c] = c < C ? Elem<TI>::load(in + (n * C + c) * HW + p) : 0.f;
 #pragma unroll
     for (int v = 0; v < 16 / VE; ++v) reinterpret_cast<Vec16*>(o + i * 16)[v] = Elem<T>::pack(f + v * VE);
   }
@@ -256,8 +256,16 @@ int launch_nhwc16_to_planar(int dt, const void* o16, float* out, int N, int C, i
 }
 int launch_planar_to_nhwc16(int dt, const float* in, void* o16, int N, int C, int HW, hipStream_t s) {
   const long npix = (long)N * HW;
-  if (dt == DT_F32) hipLaunchKernelGGL((planar_to_nhwc16_kernel<float>), dim3(ew_blocks(npix)), dim3(256), 0, s, in, (float*)o16, npix, C, HW);
-  else hipLaunchKernelGGL((planar_to_nhwc16_kernel<bf16_t>), dim3(ew_blocks(npix)), dim3(256), 0, s, in, (bf16_t*)o16, npix, C, HW);
+  if (dt == DT_F32) hipLaunchKernelGGL((planar_to_nhwc16_kernel<float, float>), dim3(ew_blocks(npix)), dim3(256), 0, s, in, (float*)o16, npix, C, HW);
+  else hipLaunchKernelGGL((planar_to_nhwc16_kernel<bf16_t, float>), dim3(ew_blocks(npix)), dim3(256), 0, s, in, (bf16_t*)o16, npix, C, HW);
+  return check_launch("planar_to_nhwc16");
+}
+// the same from a planar tensor of the storage type (the encoder's staged image, in_channels > 1)
+int launch_planar_to_nhwc16(int dt, const void* in, int in_dt, void* o16, int N, int C, int HW, hipStream_t s) {
+  if (in_dt != dt) { set_error("planar_to_nhwc16: input and output types differ"); return MMVAE_ERR_UNSUPPORTED; }
+  if (dt == DT_F32) return launch_planar_to_nhwc16(dt, static_cast<const float*>(in), o16, N, C, HW, s);
+  const long npix = (long)N * HW;
+  hipLaunchKernelGGL((planar_to_nhwc16_kernel<bf16_t, bf16_t>), dim3(ew_blocks(npix)), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)o16, npix, C, HW);
   return check_launch("planar_to_nhwc16");
 }
 

@@ -170,7 +170,7 @@ const Plan& Net::plan(int N) {
   const long e = (long)esz();
   auto take = [&](long bytes) { long o = cur; cur = align_up(cur + std::max(bytes, 16L), 256); return o; };
   auto act = [&](long elems) { maxact = std::max(maxact, elems * e); return take(elems * e); };
-  P.x_t = act((long)N * cfg.S * cfg.S);
+  P.x_t = act((long)N * cfg.in_ch * cfg.S * cfg.S);
   P.y0 = act((long)N * H1 * W1 * 32);
   for (Block& B : enc) {
     const long n = (long)N * B.Hout * B.Wout * B.C;
@@ -186,7 +186,8 @@ const Plan& Net::plan(int N) {
   P.cvec = take(512 * 4);
   P.r_raw = take((long)N * cfg.out_ch * Sd * Sd * 4);
   P.d_raw = take((long)N * cfg.out_ch * Sd * Sd * 4);
-  P.col = act((long)N * H1 * W1 * 32);
+  // im2col of the 1-channel image; in_channels > 1: the image as NHWC with 16 zero-padded channels (the generic weight gradient's G operand)
+  P.col = act(cfg.in_ch == 1 ? (long)N * H1 * W1 * 32 : (long)N * cfg.S * cfg.S * 16);
   P.packed = take(n_packed * e);
   P.bnws = take(n_bnws * 4);
   P.partials = take(2 * kPartialFloats * 4);       // second half: the shortcut branch running on the side stream
@@ -414,7 +415,7 @@ int Net::packs_enc_fwd(const float* params, char* base, hipStream_t s) {
     const int cpad = dt() == DT_F32 ? 4 : 8;
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + stem.off; pa.dst = base + P.packed + stem_pack * (long)esz();
-    pa.cols = 32; pa.K = cpad; pa.K_valid = 1; pa.ntaps = 25; pa.s_col = 25; pa.s_k = 25; pa.scale = 1.f;
+    pa.cols = 32; pa.K = cpad; pa.K_valid = cfg.in_ch; pa.ntaps = 25; pa.s_col = 25 * cfg.in_ch; pa.s_k = 25; pa.scale = 1.f;
     for (int t = 0; t < 25; ++t) pa.tap_off[t] = t;
     MM_TRY(launch_pack(dt(), pa, s));
   }
@@ -491,7 +492,6 @@ int Net::stage_labels(int N, const void* labels, int label_bytes, float mean, fl
 
 int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, long long* nbt, void* ws, size_t ws_bytes,
                      float* mu, float* logvar, int training, hipStream_t s, bool staged) {
-  if (cfg.in_ch != 1) { set_error("encoder: in_channels=%d unsupported (1)", cfg.in_ch); return MMVAE_ERR_UNSUPPORTED; }
   if (Hf > 2) { set_error("encoder: image size %d unsupported (final map %dx%d)", cfg.S, Hf, Wf); return MMVAE_ERR_UNSUPPORTED; }
   const Plan& P = plan(N);
   if (ws_bytes < P.bytes) { set_error("workspace too small: %zu < %zu", ws_bytes, P.bytes); return MMVAE_ERR_WORKSPACE; }
@@ -502,22 +502,18 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   pack_batch_begin();                       // every weight re-pack of this entry point in ONE launch
   MM_TRY(packs_enc_fwd(params, base, s));
   MM_TRY(pack_batch_flush(dt(), s));
-  if (!staged) MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * S * S, s));
+  if (!staged) MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * cfg.in_ch * S * S, s));
   if (cfg.in_ch == 1 && stem_fwd_stream_ok(dt(), S)) {
     const int np = launch_stem_fwd_stream(dt(), base + P.x_t, params + stem.off, base + P.y0, stats, N, S, s);
     MM_TRY(np);
     if (training) MM_TRY(bn_train(bn0, params, bnbuf, nbt, base, np, (double)N * H1 * W1, s));
   } else {
-    // stem Conv2d(1 -> 32, k5 s2 p2) (model.py:94): the 1-channel image is staged as a zero-padded VE-channel NHWC patch
-    // in LDS and runs through the MFMA patch-tile kernel; BatchNorm statistics come out of its epilogue.
+    // stem Conv2d(in_channels -> 32, k5 s2 p2) (model.py:94): the planar image (in_channels <= 4 planes) is staged as a zero-padded
+    // VE-channel NHWC patch in LDS and runs through the MFMA patch-tile kernel; BatchNorm statistics come out of its epilogue.
     const int cpad = dt() == DT_F32 ? 4 : 8;
-    PackArgs pa; std::memset(&pa, 0, sizeof(pa));
-    pa.src = params + stem.off; pa.dst = base + P.packed + stem_pack * (long)esz();
-    pa.cols = 32; pa.K = cpad; pa.K_valid = 1; pa.ntaps = 25; pa.s_col = 25; pa.s_k = 25; pa.scale = 1.f;
-    for (int t = 0; t < 25; ++t) pa.tap_off[t] = t;
     GatherArgs a; std::memset(&a, 0, sizeof(a));
-    a.x = base + P.x_t; a.w = pa.dst; a.y = base + P.y0; a.stats = stats;
-    a.x_planar = 2; a.x_planes = 1;
+    a.x = base + P.x_t; a.w = base + P.packed + stem_pack * (long)esz(); a.y = base + P.y0; a.stats = stats;
+    a.x_planar = 2; a.x_planes = cfg.in_ch;
     a.N = N; a.Hi = S; a.Wi = S; a.Cin = cpad; a.Ho = H1; a.Wo = W1; a.Cout = 32; a.SI = 2; a.SO = 1;
     a.nphase = 1; a.phases[0] = Phase{0, 0, H1, W1, 25, 0, 0};
     for (int kh = 0; kh < 5; ++kh) for (int kw = 0; kw < 5; ++kw) a.taps[kh * 5 + kw] = Tap{kh - 2, kw - 2};
@@ -626,7 +622,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
       // the stem's finalize at the very end waits for THIS, not for the whole side stream (whose last weight gradients may still run)
       if (side_state_ == 1 && hipEventRecord(gram_ev_, side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
     }
-    if (!stem_bwd_fused() && stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
+    if (!stem_bwd_fused() && cfg.in_ch == 1 && stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
     pa.cols = 256; pa.K = Ch; pa.ntaps = 1; pa.s_col = 1; pa.s_k = 256; pa.scale = 1.0f / nt;
@@ -730,7 +726,13 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     WgradArgs a; std::memset(&a, 0, sizeof(a));
     a.P = base + P.dy1[ds]; a.dW = grads + stem.off; a.scratch = wscratch_;
     a.N = N; a.Hp = H1; a.Wp = W1; a.Ca = 32; a.scale = 1.f;
-    if (stem_im2col) {
+    if (cfg.in_ch > 1) {
+      // in_channels > 1 (main.py:555): G = the image as NHWC with 16 zero-padded channels, the generic 25-tap weight gradient
+      MM_TRY(launch_planar_to_nhwc16(dt(), static_cast<const void*>(base + P.x_t), dt(), base + P.col, N, cfg.in_ch, cfg.S * cfg.S, wsm));
+      a.G = base + P.col; a.Hg = cfg.S; a.Wg = cfg.S; a.Cb = 16; a.Cb_valid = cfg.in_ch;
+      a.stride = 2; a.pad = 2; a.ksz = 5; a.sA = 25 * cfg.in_ch; a.sB = 25; a.ntaps = 25;
+      for (int t = 0; t < 25; ++t) a.tap_off[t] = t;
+    } else if (stem_im2col) {
       // im2col of the 1-channel image (25 taps padded to 32 columns) + the MFMA weight-gradient kernel as a 1x1 conv
       if (wsm == s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wsm));   // else: done early
       a.G = base + P.col; a.Hg = H1; a.Wg = W1; a.Cb = 32; a.Cb_valid = 25;

@@ -47,6 +47,8 @@ CASES = OrderedDict([
     ("gauss_s32",     dict(z=32,  S=32, N=8,  out_ch=1, rsample=True,  kl=1, mmd=0,  sigma=0.1, weight=None)),
     ("gauss_s28",     dict(z=32,  S=28, N=8,  out_ch=1, rsample=True,  kl=1, mmd=0,  sigma=0.1, weight=None)),
     ("cat_s56",       dict(z=32,  S=56, N=4,  out_ch=2, rsample=True,  kl=1, mmd=0,  sigma=0.0, weight="ones")),
+    # --input_channels 3 (main.py:555): Gaussian reconstruction of a 3-plane image (decoder_out_channels == in_channels, main.py:130)
+    ("gauss_rgb",     dict(z=32,  S=64, N=4,  out_ch=3, rsample=True,  kl=1, mmd=0,  sigma=0.1, weight=None, in_ch=3)),
 ])
 
 TRAJ = OrderedDict([
@@ -58,7 +60,7 @@ TRAJ = OrderedDict([
 def ref_model(cfg):
     sys.path.insert(0, REF)
     import model as refmodel  # the reference's model.py
-    m = refmodel.VAE(1, 32, cfg["out_ch"], 2, cfg["z"], False, False, 4, "ReLu", 1, cfg["kl"], cfg["mmd"],
+    m = refmodel.VAE(cfg.get("in_ch", 1), 32, cfg["out_ch"], 2, cfg["z"], False, False, 4, "ReLu", 1, cfg["kl"], cfg["mmd"],
                      cfg["rsample"], cfg["sigma"], cfg["S"])
     return m
 
@@ -91,7 +93,8 @@ def draw_noise(seed, n, z, rsample):
 
 
 def run_case(name, cfg):
-    spec = O.state_spec(1, cfg["z"], cfg["out_ch"], cfg["S"], cfg["rsample"])
+    in_ch = cfg.get("in_ch", 1)
+    spec = O.state_spec(in_ch, cfg["z"], cfg["out_ch"], cfg["S"], cfg["rsample"])
     state = O.filled_state(spec, seed=0)
     ref = ref_model(cfg)
     assert list(ref.state_dict().keys()) == [k for k, _, _ in spec], "state_dict key order differs"
@@ -99,9 +102,9 @@ def run_case(name, cfg):
         assert tuple(rv.shape) == tuple(shape), (k, rv.shape, shape)
     ref.load_state_dict(state)
     ref.train(True)
-    labels = O.synthetic_labels(cfg["N"], cfg["S"], seed=1234)
-    image = O.normalise(labels, cfg["S"])
-    categorical = cfg["out_ch"] > 1
+    labels = O.synthetic_labels(cfg["N"] * in_ch, cfg["S"], seed=1234)
+    image = O.normalise(labels, cfg["S"]).view(cfg["N"], in_ch, cfg["S"], cfg["S"])
+    categorical = cfg["out_ch"] > in_ch                              # model.py:399
     target = labels if categorical else image
     args = types.SimpleNamespace(data_ratio_of_labels=class_weight(cfg))
     seed = 77
@@ -245,10 +248,13 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     assert os.path.isdir(REF), "the reference is only mounted in the build container"
+    only = sys.argv[1:]
     for name, cfg in CASES.items():
-        run_case(name, cfg)
+        if not only or name in only:
+            run_case(name, cfg)
     for name, cfg in TRAJ.items():
-        run_traj(name, cfg)
+        if not only or name in only:
+            run_traj(name, cfg)
 
 
 if __name__ == "__main__":

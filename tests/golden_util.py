@@ -11,7 +11,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RATIOS_Q2 = np.array([0.9479, 0.0521], dtype=np.float64)
 
 CASE_NAMES = ["c1_gauss", "c1_cat_w1", "c1_cat_wr", "gauss_mmd10", "gauss_norsamp", "gauss_z128",
-              "gauss_z512", "gauss_s32", "gauss_s28", "cat_s56"]
+              "gauss_z512", "gauss_s32", "gauss_s28", "cat_s56", "gauss_rgb"]
+
+
+def case_inputs(O, cfg, seed):
+    """labels (N * in_ch frames of i.i.d. Bernoulli pixels), the normalised image (N, in_ch, S, S) and the loss target of a golden case
+    (oracle/make_golden.py run_case)."""
+    in_ch = cfg.get("in_ch", 1)
+    labels = O.synthetic_labels(cfg["N"] * in_ch, cfg["S"], seed=seed)
+    image = O.normalise(labels, cfg["S"]).view(cfg["N"], in_ch, cfg["S"], cfg["S"])
+    categorical = cfg["out_ch"] > in_ch
+    return labels, image, categorical, (labels if categorical else image)
 TRAJ_NAMES = ["traj_gauss", "traj_cat"]
 
 

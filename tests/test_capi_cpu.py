@@ -57,7 +57,7 @@ def test_unsupported_configurations_fail_loudly(pkg):
     with pytest.raises(L.MmvaeError):
         M.VAE(1, 24)                                  # PixelCNN intermediate_channels not a multiple of 16
     with pytest.raises(L.MmvaeError):
-        M.VAE(3, 32, 1, 2, 32, False, False)          # in_channels != 1
+        M.VAE(5, 32, 4, 2, 32, False, False)          # in_channels > 4
     with pytest.raises(L.MmvaeError):
         M.VAE(1, 32, 1, 2, 20, False, False)          # z not a multiple of 8
     m = M.VAE(1, 32, 1, 2, 32, False, False)

@@ -32,7 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from golden_util import CASE_NAMES, TRAJ_NAMES, LabelLoader, load, make_args  # noqa: E402
+from golden_util import CASE_NAMES, TRAJ_NAMES, LabelLoader, case_inputs, load, make_args  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -51,9 +51,9 @@ def _M():
 
 def build_model(cfg, dt, O):
     M = _M()
-    m = M.VAE(1, 32, cfg["out_ch"], 2, cfg["z"], False, False, 4, "ReLu", 1, cfg["kl"], cfg["mmd"], cfg["rsample"], cfg["sigma"],
+    m = M.VAE(cfg.get("in_ch", 1), 32, cfg["out_ch"], 2, cfg["z"], False, False, 4, "ReLu", 1, cfg["kl"], cfg["mmd"], cfg["rsample"], cfg["sigma"],
               cfg["S"], compute_dtype=dt)
-    spec = O.state_spec(1, cfg["z"], cfg["out_ch"], cfg["S"], cfg["rsample"])
+    spec = O.state_spec(cfg.get("in_ch", 1), cfg["z"], cfg["out_ch"], cfg["S"], cfg["rsample"])
     m.load_state_dict(O.filled_state(spec, seed=0))
     return m.to("cuda").train(), spec
 
@@ -64,10 +64,8 @@ def run_case(name, dt, O, verbose=False):
     n, z, S = cfg["N"], cfg["z"], cfg["S"]
     dev = torch.device("cuda")
     m, spec = build_model(cfg, dt, O)
-    labels = O.synthetic_labels(n, S, seed=int(g["labels_seed"]))
-    image = O.normalise(labels, S)
-    categorical = cfg["out_ch"] > 1
-    target = (labels if categorical else image).to(dev)
+    labels, image, categorical, target = case_inputs(O, cfg, int(g["labels_seed"]))
+    target = target.to(dev)
     if cfg["rsample"]:
         m.injected_eps = torch.from_numpy(g["eps"]).view(n, z, 1, 1).to(dev)
     m.injected_true_samples = torch.from_numpy(g["true_samples"]).to(dev)
@@ -192,12 +190,9 @@ def test_bf16_gradient_noise_not_worse_than_torch_autocast(name, oracle):
     n, z, S = cfg["N"], cfg["z"], cfg["S"]
     dev = torch.device("cuda")
     rs = bool(cfg["rsample"])
-    spec = O.state_spec(1, z, cfg["out_ch"], S, rs)
+    spec = O.state_spec(cfg.get("in_ch", 1), z, cfg["out_ch"], S, rs)
     pn = [k for k, _, kind in spec if kind in ("conv", "convT", "bias", "bn_w", "bn_b")]
-    labels = O.synthetic_labels(n, S, seed=int(g["labels_seed"]))
-    image = O.normalise(labels, S)
-    categorical = cfg["out_ch"] > 1
-    target = labels if categorical else image
+    labels, image, categorical, target = case_inputs(O, cfg, int(g["labels_seed"]))
     eps = torch.from_numpy(g["eps"]).view(n, z, 1, 1) if "eps" in g.files else None      # (require_rsample=False: no noise)
     ts = torch.from_numpy(g["true_samples"])
     args = make_args(cfg)

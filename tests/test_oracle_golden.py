@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASE_NAMES, TRAJ_NAMES, LabelLoader, load, make_args
+from golden_util import CASE_NAMES, TRAJ_NAMES, LabelLoader, case_inputs, load, make_args
 
 RTOL = 2e-6
 
@@ -20,16 +20,13 @@ def test_oracle_matches_reference_golden(name, oracle):
     O = oracle
     g, cfg = load(name)
     n, z, S = cfg["N"], cfg["z"], cfg["S"]
-    spec = O.state_spec(1, z, cfg["out_ch"], S, cfg["rsample"])
+    spec = O.state_spec(cfg.get("in_ch", 1), z, cfg["out_ch"], S, cfg["rsample"])
     sd = O.filled_state(spec, seed=0)
     params = [k for k, _, kind in spec if kind in ("conv", "convT", "bias", "bn_w", "bn_b")]
     assert params == [str(s) for s in g["grad_names"]]
     for k in params:
         sd[k].requires_grad_(True)
-    labels = O.synthetic_labels(n, S, seed=int(g["labels_seed"]))
-    image = O.normalise(labels, S)
-    categorical = cfg["out_ch"] > 1
-    target = labels if categorical else image
+    labels, image, categorical, target = case_inputs(O, cfg, int(g["labels_seed"]))
     eps = torch.from_numpy(g["eps"]).view(n, z, 1, 1) if cfg["rsample"] else None
     ts = torch.from_numpy(g["true_samples"])
     args = make_args(cfg)
