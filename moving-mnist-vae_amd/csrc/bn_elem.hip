@@ -219,6 +219,27 @@ int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm
   return check_launch("bn_eval_affine");
 }
 
+// Inference (model.eval(), reference model.py:353-362): every BatchNorm of an entry point folded into its per-channel (scale, shift) pair from the
+// running statistics in ONE launch -- the consumers' prologues apply them, no statistics, no per-layer finalize.
+__global__ void bn_fold_eval_kernel(BnFoldTable t, const float* __restrict__ params, const float* __restrict__ bnbuf, float* __restrict__ bnws, float eps) {
+  const BnFoldEntry e = t.e[blockIdx.x];
+  for (int c = threadIdx.x; c < e.C; c += blockDim.x) {
+    const float istd = 1.0f / sqrtf(bnbuf[e.rv_off + c] + eps);
+    const float sc = params[e.g_off + c] * istd;
+    bnws[e.scale_off + c] = sc / e.in_scale;              // the conv output in memory is in_scale * y (fp8 weight scale)
+    bnws[e.shift_off + c] = params[e.b_off + c] - bnbuf[e.rm_off + c] * sc;
+  }
+}
+int launch_bn_fold_eval(const BnFoldEntry* entries, int n, const float* params, const float* bnbuf, float* bnws, float eps, hipStream_t s) {
+  for (int i = 0; i < n; i += kBnFoldMax) {
+    BnFoldTable t;
+    const int m = n - i < kBnFoldMax ? n - i : kBnFoldMax;
+    for (int j = 0; j < m; ++j) t.e[j] = entries[i + j];
+    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3(m), dim3(256), 0, s, t, params, bnbuf, bnws, eps);
+  }
+  return check_launch("bn_fold_eval");
+}
+
 // ---------------------------------------------------------------- forward elementwise
 template <typename T, bool TWO>
 __global__ void affine_join_kernel(const T* __restrict__ a, const float* __restrict__ sa, const float* __restrict__ ba,

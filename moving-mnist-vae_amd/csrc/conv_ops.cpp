@@ -158,6 +158,17 @@ static void wgrad_args(WgradArgs& a, const ConvGeom& g, int N, const void* P, in
   for (int t = 0; t < kk && t < 25; ++t) a.tap_off[t] = t;
 }
 
+// A 3x3 stride-2 conv and the 1x1 stride-2 shortcut on the same input (a residual block's conv1 / downsample.0): both weight gradients from one
+// pass over the block input.  Returns 1 when taken, 0 when the shapes are not the stream kernel's (the caller runs the two separately), <0 on error.
+int op_run_wgrad_pair(int dt, const ConvGeom& g, const ConvGeom& gs, int N, const void* P, const void* P2, int Hs, int Ws, const void* G, int Hl, int Wl,
+                      const float* proG_s, const float* proG_b, int proG_relu, float* dW, float* dW2, hipStream_t s, float* scratch, float scale,
+                      float scale2) {
+  if (g.k != 3 || g.p != 1 || gs.k != 1 || gs.p != 0 || gs.s != g.s || gs.D0 != g.D0 || gs.D1 != g.D1) return 0;
+  WgradArgs a;
+  wgrad_args(a, g, N, P, Hs, Ws, nullptr, nullptr, 0, G, Hl, Wl, proG_s, proG_b, proG_relu, dW, scratch, scale);
+  return try_wgrad_stream_pair(dt, a, P2, dW2, scale2, s);
+}
+
 bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl) {
   if (g.k * g.k > 25) return false;
   WgradArgs a;

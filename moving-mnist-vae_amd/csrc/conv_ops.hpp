@@ -37,6 +37,9 @@ int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* 
 int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                  const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s,
                  float* scratch = nullptr, float scale = 1.f);
+int op_run_wgrad_pair(int dt, const ConvGeom& g, const ConvGeom& gs, int N, const void* P, const void* P2, int Hs, int Ws, const void* G, int Hl, int Wl,
+                      const float* proG_s, const float* proG_b, int proG_relu, float* dW, float* dW2, hipStream_t s, float* scratch, float scale,
+                      float scale2);
 
 // Weight gradient AND the data gradient w.r.t. the small-side tensor P in ONE pass over G (wgrad_stream_kernel with DG; the 16 -> 16
 // channel k4 s2 layers on 32x32 -> 64x64 maps, bf16):  dW += P^T (x) G;  dP = down(G) with the conv's packed down form (+ x2 (x) w2,

@@ -36,6 +36,10 @@ struct WStreamArgs {
   // in LDS anyway -- as one more image of the block's partial: [NT + 1][16][16]
   // BatchNorm-backward partial sums of the BN that produced P (DG + PRO_P): g = dx * (P*scale+shift > 0); rows [block][2][16]: sum g, sum g * P
   float* bn_part;
+  // (P2) a second P operand on the same grid whose layer reads the SAME G pixels through its only tap, the centre one: the 1x1 stride-S
+  // shortcut next to a 3x3 stride-S conv (encoder.layer1: conv1 and downsample.0 from one read of the block input).  Its weight gradient
+  // dW2[a][b] = sum P2[n,h,w,a] * G[n, S*h, S*w, b] is one more image of the partial, [NT + 1][CA][CB]
+  const void* P2;
 };
 
 // KS x KS taps, stride S, padding PAD; WP = P row width: one step = 32 P pixels = one MFMA K-step = ONE row of 32 or TWO rows of 16
@@ -50,12 +54,13 @@ struct WStreamArgs {
 // ST (with DG and PRO_P): P is a pre-BatchNorm tensor whose BN+ReLU is the prologue; the pass also reduces that BatchNorm's backward sums
 // (sum g, sum g*P over all pixels, g = dx masked by the ReLU) from the data gradient it has just computed -- the bn_bwd_reduce launch
 // that would re-read dx and P disappears.
-template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST, int NW = 4>
+template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST, int NW = 4, bool P2 = false>
 __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a) {
   static_assert(WP == 32 || WP == 16, "32 P pixels per step: one row of 32 or two rows of 16");
   static_assert(!ST || (DG && PRO_P && !X2 && CA16 == 1), "BatchNorm sums ride on the data gradient of a prologue'd 16-channel P");
   static_assert(!DG || (CB16 == 1 && KS == 4 && S == 2), "fused data gradient: 16 G channels, 4x4 taps, stride 2");
   static_assert(!X2 || DG, "the second source rides on the data gradient");
+  static_assert(!P2 || (!DG && !X2 && !ST && PAD < KS), "the centre-tap companion rides on the plain weight-gradient pass");
   constexpr int RP = 32 / WP;                              // P rows per step
   constexpr int CA = CA16 * 16, CB = CB16 * 16;
   constexpr int CAB = CA16 * 32, CBB = CB16 * 32;          // bytes per P / G pixel
@@ -67,9 +72,10 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
   constexpr int PB = 32 * CAB;                             // bytes of a step's P rows
   constexpr int X2B = X2 ? 32 * 32 : 0;                    // bytes of the x2 rows (16 channels)
   constexpr int RAWB = ST ? PB : 0;                        // raw copy of the P rows (before the prologue) for the BatchNorm sums
-  constexpr int WAVE_LDS = NSLOT * ROWB + PB + X2B + RAWB;
+  constexpr int P2B = P2 ? PB : 0;                         // the companion layer's P rows
+  constexpr int WAVE_LDS = NSLOT * ROWB + PB + X2B + RAWB + P2B;
   constexpr int NT = KS * KS;
-  constexpr int WSIZE = NT * CA * CB + (X2 ? 16 * CA : 0); // floats of a partial image (X2: + the 1x1 conv's [16][CA])
+  constexpr int WSIZE = NT * CA * CB + (X2 ? 16 * CA : 0) + (P2 ? CA * CB : 0);   // floats of a partial image (X2: + the 1x1 conv's [16][CA]; P2: + [CA][CB])
   constexpr bool WD_LDS = DG && CA16 > 1;                  // the data gradient's A fragments live in block-shared LDS
   constexpr int WDB = WD_LDS ? CA16 * (NT / 2) * 1024 : 0;
   // (the flush image, WSIZE floats + 128 floats of BatchNorm sums, aliases the rings: the launcher allocates the larger of the two)
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
   char* prow = ring + NSLOT * ROWB;
   char* x2row = prow + PB;
   char* rawrow = x2row + X2B;
+  char* prow2 = rawrow + RAWB;
   constexpr int Wg = S * WP;                               // G row width (the launcher checks it)
   constexpr int grow_bytes = Wg * CBB;                     // bytes of a G row in memory
   constexpr int GV = (GR * grow_bytes + 1023) / 1024;      // 16-byte vectors per lane for the GR rows of a step
@@ -132,6 +139,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
 #pragma unroll
       for (int cb = 0; cb < CB16; ++cb) acc[k][ca][cb] = (f32x4){0, 0, 0, 0};
 
+  f32x4 accD[P2 ? CA16 : 1][P2 ? CB16 : 1];                 // P2: the centre-tap companion's weight gradient
+#pragma unroll
+  for (int ca = 0; ca < (P2 ? CA16 : 1); ++ca)
+#pragma unroll
+    for (int cb = 0; cb < (P2 ? CB16 : 1); ++cb) accD[ca][cb] = (f32x4){0, 0, 0, 0};
   f32x4 acc2[CA16];                                         // X2: the 1x1 conv's weight gradient [x2 channel][P channel]
 #pragma unroll
   for (int ca = 0; ca < CA16; ++ca) acc2[ca] = (f32x4){0, 0, 0, 0};
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
   const int nq = a.HS / RP + 1;                             // steps of a unit: the priming step + one per RP P rows
 
   // registers of the step in flight
-  Vec16 gv[GV], pv[PV], xv = Vec16{{0, 0, 0, 0}};
+  Vec16 gv[GV], pv[PV], pv2[P2 ? PV : 1], xv = Vec16{{0, 0, 0, 0}};
   auto issue = [&](int u, int q) {
     const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
     const int hrow = h0 + RP * (q - 1);                     // first P row of the step (q = 0: the rows above the strip's first step)
@@ -188,6 +200,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
       for (int k = 0; k < PV; ++k)
         pv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(Pm) + (((long)n * a.Hp + hrow) * WP) * CAB + (lane + 64 * k) * 16);
       if constexpr (X2) xv = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.x2) + (((long)n * a.Hp + hrow) * WP) * 32 + lane * 16);
+      if constexpr (P2) {
+#pragma unroll
+        for (int k = 0; k < PV; ++k)
+          pv2[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.P2) + (((long)n * a.Hp + hrow) * WP) * CAB + (lane + 64 * k) * 16);
+      }
     }
   };
   auto commit = [&](int u, int q) {
@@ -226,6 +243,10 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
         *reinterpret_cast<Vec16*>(prow + (lane + 64 * k) * 16) = v;
       }
       if constexpr (X2) *reinterpret_cast<Vec16*>(x2row + lane * 16) = xv;
+      if constexpr (P2) {
+#pragma unroll
+        for (int k = 0; k < PV; ++k) *reinterpret_cast<Vec16*>(prow2 + (lane + 64 * k) * 16) = pv2[k];
+      }
     }
   };
 
@@ -245,6 +266,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
       Vec16 af[CA16];
 #pragma unroll
       for (int ca = 0; ca < CA16; ++ca) af[ca] = FragOps<bf16_t>::load(prow, offA[0] + 32 * ca, offA[1] + 32 * ca);
+      Vec16 af2[P2 ? CA16 : 1];
+      if constexpr (P2) {
+#pragma unroll
+        for (int ca = 0; ca < CA16; ++ca) af2[ca] = FragOps<bf16_t>::load(prow2, offA[0] + 32 * ca, offA[1] + 32 * ca);
+      }
 #pragma unroll
       for (int kh = 0; kh < KS; ++kh) {
         // (two rows per step: the lane's k-slice belongs to P row lrow, whose G rows are S further down the ring)
@@ -256,6 +282,12 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
             const Vec16 bf = FragOps<bf16_t>::load(rowp, offB[0] + kw * CBB + 32 * cb, offB[1] + kw * CBB + 32 * cb);
 #pragma unroll
             for (int ca = 0; ca < CA16; ++ca) acc[kh * KS + kw][ca][cb] = mma_bf16(af[ca], bf, acc[kh * KS + kw][ca][cb]);
+            if constexpr (P2) {
+              if (kh == PAD && kw == PAD) {                  // the centre tap reads G[S*h][S*w]: the 1x1 stride-S layer's only pixel
+#pragma unroll
+                for (int ca = 0; ca < CA16; ++ca) accD[ca][cb] = mma_bf16(af2[ca], bf, accD[ca][cb]);
+              }
+            }
           }
         }
       }
@@ -365,6 +397,17 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
             *p = (w == 0 ? 0.f : *p) + acc2[ca][j];
           }
       }
+      if constexpr (P2) {
+#pragma unroll
+        for (int ca = 0; ca < CA16; ++ca)
+#pragma unroll
+          for (int cb = 0; cb < CB16; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float* p = img + (NT * CA + ca * 16 + 4 * gq + j) * CB + cb * 16 + r;
+              *p = (w == 0 ? 0.f : *p) + accD[ca][cb][j];
+            }
+      }
     }
     __syncthreads();
   }
@@ -388,17 +431,17 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
   for (int i = t; i < WSIZE / 4; i += 64 * NW) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(img)[i];
 }
 
-template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST = false, int NW = 4>
+template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST = false, int NW = 4, bool P2 = false>
 static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
   constexpr int RP = 32 / WP;
   constexpr int WL = S * (WP - 1) + KS;
   constexpr int NSLOT = S * (RP - 1) + KS + S * RP;
-  constexpr size_t rings = NW * (size_t)(NSLOT * WL * CB16 * 32 + 32 * CA16 * 32 + (X2 ? 32 * 32 : 0) + (ST ? 32 * CA16 * 32 : 0)) +
+  constexpr size_t rings = NW * (size_t)(NSLOT * WL * CB16 * 32 + 32 * CA16 * 32 + (X2 ? 32 * 32 : 0) + (ST ? 32 * CA16 * 32 : 0) + (P2 ? 32 * CA16 * 32 : 0)) +
                            ((DG && CA16 > 1) ? CA16 * (KS * KS / 2) * 1024 : 0);
-  constexpr size_t flush = ((size_t)KS * KS * CA16 * 16 * CB16 * 16 + (X2 ? 16 * CA16 * 16 : 0)) * 4 + 512;
+  constexpr size_t flush = ((size_t)KS * KS * CA16 * 16 * CB16 * 16 + (X2 ? 16 * CA16 * 16 : 0) + (P2 ? CA16 * 16 * CB16 * 16 : 0)) * 4 + 512;
   constexpr size_t lds = rings > flush ? rings : flush;
   static_assert(lds <= 160 * 1024, "one block must fit the CU's LDS");
-  auto kern = &wgrad_stream_kernel<KS, S, PAD, WP, CA16, CB16, PRO_P, PRO_G, DG, X2, ST, NW>;
+  auto kern = &wgrad_stream_kernel<KS, S, PAD, WP, CA16, CB16, PRO_P, PRO_G, DG, X2, ST, NW, P2>;
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -427,7 +470,7 @@ static int wstream_kind(int dt, const WgradArgs& a) {
   if (a.ksz == 3 && a.pad == 1 && a.Wp == 16 && a.Ca == 32 && a.Cb == 32 && !(a.proP_scale && a.proG_scale)) return a.stride == 1 ? 3 : (a.stride == 2 ? 4 : 0);
   return 0;
 }
-static int wstream_fill(const WgradArgs& a, WStreamArgs& b, int kind, bool x2 = false) {
+static int wstream_fill(const WgradArgs& a, WStreamArgs& b, int kind, bool x2 = false, bool p2 = false) {
   memset(&b, 0, sizeof(b));
   b.P = a.P; b.G = a.G; b.part = a.scratch;
   b.proP_scale = a.proP_scale; b.proP_shift = a.proP_shift; b.proP_relu = a.proP_relu;
@@ -438,7 +481,7 @@ static int wstream_fill(const WgradArgs& a, WStreamArgs& b, int kind, bool x2 = 
   const int nw = kind == 4 ? 2 : 4;
   int gx = kind == 4 ? 768 : 512;                           // two 4-wave (three 2-wave) blocks per CU
   while (gx > 8 && (long)gx * nw > b.nunits) gx -= 8;
-  const int wsize = (a.ntaps + (x2 ? 1 : 0)) * a.Ca * a.Cb;
+  const int wsize = (a.ntaps + ((x2 || p2) ? 1 : 0)) * a.Ca * a.Cb;
   if ((size_t)gx * wsize * 4 > kWgradScratchBytes) return 0;
   return gx;
 }
@@ -478,6 +521,33 @@ int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s) {
 #undef MMVAE_WS
   if (rc < 0) return rc;
   const int rc2 = wstream_reduce(a, gx, s);
+  return rc2 < 0 ? rc2 : 1;
+}
+
+// encoder.layer1: conv1 (3x3 s2 p1, 32 -> 32) and the 1x1 s2 shortcut read the same block input: both weight gradients from ONE pass over it
+// (P = d conv1 output, P2 = d shortcut output, same grid).  Returns 1 when taken, 0 when the shape is not this kernel's, <0 on error.
+int try_wgrad_stream_pair(int dt, const WgradArgs& a, const void* P2, float* dW2, float scale2, hipStream_t s) {
+  const int kind = wstream_kind(dt, a);
+  if (kind != 4 || a.proP_scale || !P2 || !dW2) return 0;
+  WStreamArgs b;
+  const int gx = wstream_fill(a, b, kind, false, true);
+  if (gx <= 0) return 0;
+  b.P2 = P2;
+  note_launch_bytes((double)a.N * 2.0 * ((double)a.Hp * a.Wp * 2 * a.Ca + (double)a.Hg * a.Wg * a.Cb));
+  const int rc = a.proG_scale ? launch_wstream_t<3, 2, 1, 16, 2, 2, false, true, false, false, false, 2, true>(b, gx, s)
+                              : launch_wstream_t<3, 2, 1, 16, 2, 2, false, false, false, false, false, 2, true>(b, gx, s);
+  if (rc < 0) return rc;
+  WgradReduceArgs u; memset(&u, 0, sizeof(u));
+  u.part = a.scratch; u.dW = a.dW; u.Ca = a.Ca; u.Cb = a.Cb; u.ntaps = a.ntaps; u.nparts = gx;
+  u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid; u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
+  u.part_stride = (long)(a.ntaps + 1) * a.Ca * a.Cb;
+  for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
+  int rc2 = launch_wgrad_reduce(u, s);
+  if (rc2 < 0) return rc2;
+  WgradReduceArgs v; memset(&v, 0, sizeof(v));
+  v.part = a.scratch + (long)a.ntaps * a.Ca * a.Cb; v.part_stride = u.part_stride; v.dW = dW2; v.Ca = a.Ca; v.Cb = a.Cb; v.ntaps = 1; v.nparts = gx;
+  v.Ca_valid = a.Ca; v.Cb_valid = a.Cb; v.sA = a.Cb; v.sB = 1; v.scale = scale2;
+  rc2 = launch_wgrad_reduce(v, s);
   return rc2 < 0 ? rc2 : 1;
 }
 

@@ -66,6 +66,7 @@ struct WgradArgs {
 };
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
 int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s);   // conv_wstream.hip: 1 = taken, 0 = not this kernel's shape, <0 error
+int try_wgrad_stream_pair(int dt, const WgradArgs& a, const void* P2, float* dW2, float scale2, hipStream_t s);
 // weight gradient + data gradient (w.r.t. P) of a 16 -> 16 channel k4 s2 layer in one pass over G (conv_wstream.hip)
 bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a);
 // dW2 (optional, with x2): the 1x1 conv's own weight gradient [16][Ca] += scale2 * x2^T (x) pro(P), from the same pass
@@ -247,6 +248,10 @@ struct BnFinalizeArgs {
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 int launch_partial_rowsum(const float* partials, int nparts, int width, float* out, hipStream_t s, int row_stride = 0);   // SyncBN: [nparts][width (stride row_stride)] -> [width]
 // eval: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
+struct BnFoldEntry { int g_off, b_off, rm_off, rv_off, scale_off, shift_off, C; float in_scale; };
+constexpr int kBnFoldMax = 96;                       // 96 x 32 B of kernel arguments per launch
+struct BnFoldTable { BnFoldEntry e[kBnFoldMax]; };
+int launch_bn_fold_eval(const BnFoldEntry* entries, int n, const float* params, const float* bnbuf, float* bnws, float eps, hipStream_t s);
 int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
                           float* scale, float* shift, hipStream_t s, float in_scale = 1.f);
 // out = relu(a*sa + ba + b*sb + bb)   (NHWC, T)

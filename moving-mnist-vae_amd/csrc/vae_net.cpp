@@ -321,6 +321,13 @@ int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const f
   return op_run_wgrad(dt(), geom(w), N, P, Hs, Ws, proP_s, proP_b, 1, G, Hl, Wl, proG_s, proG_b, 1, grads + w.off, s, wscratch_, w.wscale);
 }
 
+// conv1 (3x3 s2) + 1x1 s2 shortcut weight gradients in one stream pass: encoder.layer1's shape (bf16, 32 -> 32 channels, 32x32 -> 16x16)
+static bool wgrad_pair_ok(int dt, const ConvGeom& g, const ConvGeom& gs, int Hout, int Hin) {
+  static const bool env = [] { const char* e = getenv("MMVAE_WGRAD_PAIR"); return !(e && e[0] == '0'); }();
+  return env && dt == DT_BF16 && g.k == 3 && g.s == 2 && g.p == 1 && gs.k == 1 && gs.s == 2 && gs.p == 0 && g.D0 == 32 && g.D1 == 32 && gs.D0 == 32 &&
+         gs.D1 == 32 && Hout == 16 && Hin == 32;
+}
+
 bool Net::tail_fwd_fused() const {
   static const bool env = [] { const char* e = getenv("MMVAE_TAIL_FWD_FUSED"); return !(e && e[0] == '0'); }();
   static const bool bwd_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
@@ -359,7 +366,27 @@ int Net::bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nb
   return launch_bn_finalize(a, s);
 }
 
+int Net::fold_bn_eval(int which, const float* params, const float* bnbuf, char* base, hipStream_t s) {
+  std::vector<BnFoldEntry> tab;
+  auto add = [&](const Bn& bn, float in_scale) {
+    BnFoldEntry e;
+    e.g_off = (int)bn.g_off; e.b_off = (int)bn.b_off; e.rm_off = (int)bn.rm_off; e.rv_off = (int)bn.rv_off;
+    e.scale_off = (int)(bn.ws + 2L * align_up(bn.C, 4)); e.shift_off = (int)(bn.ws + 3L * align_up(bn.C, 4)); e.C = bn.C; e.in_scale = in_scale;
+    tab.push_back(e);
+  };
+  if (which == 0) add(bn0, 1.f); else add(dbn0, dstem.wscale);
+  for (const Block& B : which == 0 ? enc : dec) {
+    add(B.b1, B.c1.wscale); add(B.b2, B.c2.wscale);
+    if (!B.identity) add(B.bs, B.cs.wscale);
+  }
+  if (which == 1) add(bn_out, 1.f);
+  MM_TRY(launch_bn_fold_eval(tab.data(), (int)tab.size(), params, bnbuf, reinterpret_cast<float*>(base + plan_.bnws), 1e-5f, s));
+  eval_folded_ = true;
+  return MMVAE_OK;
+}
+
 int Net::bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s, float in_scale) {
+  if (eval_folded_) return MMVAE_OK;
   return launch_bn_eval_affine(params + bn.g_off, params + bn.b_off, bnbuf + bn.rm_off, bnbuf + bn.rv_off, 1e-5f, bn.C,
                                bnf(bn, base, 2), bnf(bn, base, 3), s, in_scale);
 }
@@ -502,6 +529,8 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   pack_batch_begin();                       // every weight re-pack of this entry point in ONE launch
   MM_TRY(packs_enc_fwd(params, base, s));
   MM_TRY(pack_batch_flush(dt(), s));
+  eval_folded_ = false;
+  if (!training) MM_TRY(fold_bn_eval(0, params, bnbuf, base, s));
   if (!staged) MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * cfg.in_ch * S * S, s));
   if (cfg.in_ch == 1 && stem_fwd_stream_ok(dt(), S)) {
     const int np = launch_stem_fwd_stream(dt(), base + P.x_t, params + stem.off, base + P.y0, stats, N, S, s);
@@ -670,7 +699,9 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(side_fork(s));
     MM_TRY(run_wgrad(B.c2, N, base + dy2o, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
                      bnf(B.b1, base, 3), grads, wsm));
-    if (!B.identity) MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    // (encoder.layer1: the shortcut's weight gradient rides on conv1's pass over the block input, below)
+    const bool pair = !B.identity && !B.c1.fp8 && !B.cs.fp8 && wgrad_pair_ok(dt(), geom(B.c1), geom(B.cs), B.Hout, B.Hin);
+    if (!B.identity && !pair) MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(run_up(B.c2, base, N, base + dy2o, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
     // bn1 + relu backward
     np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
@@ -681,7 +712,14 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
                                B.C, s));
     // conv1 (3x3) and the 1x1 s2 shortcut: weight gradients, then d_xin = dgrad(conv1) + dgrad(shortcut)
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c1, N, base + dy1o, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    int taken = 0;
+    if (pair) {
+      taken = op_run_wgrad_pair(dt(), geom(B.c1), geom(B.cs), N, base + dy1o, base + dyso, B.Hout, B.Wout, xin, B.Hin, B.Win, xs, xb, 1,
+                                grads + B.c1.off, grads + B.cs.off, wsm, wscratch_, B.c1.wscale, B.cs.wscale);
+      MM_TRY(taken);
+      if (!taken) MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    }
+    if (!taken) MM_TRY(run_wgrad(B.c1, N, base + dy1o, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     MM_TRY(side_mark(i));
     if (B.identity)     // d_xin already holds the shortcut's share: the main path's data gradient is added to it
       MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
@@ -760,6 +798,8 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   pack_batch_begin();
   MM_TRY(packs_dec_fwd(params, base, s));
   MM_TRY(pack_batch_flush(dt(), s));
+  eval_folded_ = false;
+  if (!training) MM_TRY(fold_bn_eval(1, params, bnbuf, base, s));
   MM_TRY(launch_convert(DT_F32, dt(), encv, base + P.enc_t, (long)N * cfg.z, s));
   // stem ConvTranspose2d(z -> 128, k2) on the 1x1 latent (model.py:159-161,182)
   int np = run_up(dstem, base, N, base + P.enc_t, 1, 1, base + P.y0d, 2, 2, nullptr, nullptr, 0, stats, 0, s);
