@@ -754,6 +754,8 @@ __global__ __launch_bounds__(256, (OC1 && !WG) ? 3 : 2) void tail_join_bwd_kerne
 //     the matrix pipe per wave and tile).  x hi / lo go through two wave-private bf16 LDS patches [pixel][16] and come back channel-major
 //     (ds_read_b64_tr_b16); B = 8 consecutive d_raw values per lane (tap = r < 9).
 // Same tiles, d_raw staging, partial-row layouts and fixed summation order as the VALU form.
+// F8I: y0 / y1 are e4m3 bytes (fp8 mode's storage of these two tensors): a lane's 4 channels of a pixel are one dword
+template <bool F8I>
 __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, const float* __restrict__ ms, const float* __restrict__ mb,
                                                                   const float* __restrict__ ms1, const float* __restrict__ mb1,
                                                                   const bf16_t* __restrict__ y0, const bf16_t* __restrict__ y1,
@@ -799,8 +801,13 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt) {
       const long e = ((long)t * PT + p0 + 16 * pt + r) * 16 + 4 * gq;
-      q0[pt] = *reinterpret_cast<const uint2*>(y0 + e);
-      q1[pt] = *reinterpret_cast<const uint2*>(y1 + e);
+      if constexpr (F8I) {
+        q0[pt] = make_uint2(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(y0) + e), 0u);
+        q1[pt] = make_uint2(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(y1) + e), 0u);
+      } else {
+        q0[pt] = *reinterpret_cast<const uint2*>(y0 + e);
+        q1[pt] = *reinterpret_cast<const uint2*>(y1 + e);
+      }
     }
     const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;      // uniform
     const float* dp = tg.d_raw + (long)n * hw;
@@ -837,10 +844,9 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
       for (int k = 0; k < 4; ++k)
         bf.w[k] = __builtin_amdgcn_perm(__float_as_uint(dv[2 * k + 1]), __float_as_uint(dv[2 * k]), 0x07060302u);     // the two upper halves
       const f32x4 g = mma_bf16(wA, bf, (f32x4){0.f, 0.f, 0.f, 0.f});
-      const float f0[4] = {__uint_as_float(c0v[pt].x << 16), __uint_as_float(c0v[pt].x & 0xffff0000u), __uint_as_float(c0v[pt].y << 16),
-                           __uint_as_float(c0v[pt].y & 0xffff0000u)};
-      const float f1[4] = {__uint_as_float(c1v[pt].x << 16), __uint_as_float(c1v[pt].x & 0xffff0000u), __uint_as_float(c1v[pt].y << 16),
-                           __uint_as_float(c1v[pt].y & 0xffff0000u)};
+      float f0[4], f1[4];
+      if constexpr (F8I) { unpack4_fp8(c0v[pt].x, f0); unpack4_fp8(c1v[pt].x, f1); }
+      else { unpack4_bf16(c0v[pt], f0); unpack4_bf16(c1v[pt], f1); }
       float x[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -995,7 +1001,8 @@ template <bool APPLY>
 static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                             const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
                             const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, float* partials, float* wpartials,
-                            hipStream_t s) {
+                            hipStream_t s, int f8in = 0) {
+  if (f8in && (APPLY || !wpartials || dt == DT_F32 || OC != 1 || W < 32)) { set_error("tail_join_bwd: e4m3 y2 / ys only in the one-plane MFMA reduce pass"); return MMVAE_ERR_UNSUPPORTED; }
   if (wpartials && (APPLY || OC != 1)) { set_error("tail_join_bwd: fused wgrad needs the one-plane reduce pass"); return MMVAE_ERR_UNSUPPORTED; }
   if (!tail_join_fusable(dt, OC, N, H, W)) { set_error("tail_join_bwd: OC=%d H=%d W=%d not supported", OC, H, W); return MMVAE_ERR_UNSUPPORTED; }
   const int VE = dt == DT_F32 ? 4 : 8, cv = 16 / VE, pt = 256 / cv;
@@ -1029,8 +1036,9 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
       const int nb = ntiles < 1024 ? ntiles : 1024;                  // four blocks per CU (114 VGPRs): one resident round (314 us; 768: 345, 512: 411)
       const int tf = ((pt / W + 2) * (W + 2) + 3) & ~3;
       const size_t lds = ((size_t)4 * (tf + 8) + 4 * 512 + 192 + 576) * sizeof(float);
-      hipLaunchKernelGGL(tail_reduce_mfma_kernel, dim3(nb), dim3(256), lds, s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, (const bf16_t*)y1, partials, wpartials);
-      note_launch_bytes((double)N * H * W * (2 * 16 * 2.0 + 4.0));
+      if (f8in) hipLaunchKernelGGL(tail_reduce_mfma_kernel<true>, dim3(nb), dim3(256), lds, s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, (const bf16_t*)y1, partials, wpartials);
+      else hipLaunchKernelGGL(tail_reduce_mfma_kernel<false>, dim3(nb), dim3(256), lds, s, tg, ms, mb, ms1, mb1, (const bf16_t*)y0, (const bf16_t*)y1, partials, wpartials);
+      note_launch_bytes((double)N * H * W * (2 * 16 * (f8in ? 1.0 : 2.0) + 4.0));
       const int rcm = check_launch("tail_reduce_mfma");
       return rcm ? rcm : nb;
     }
@@ -1049,9 +1057,9 @@ static int launch_tail_join(int dt, const float* d_raw, const float* w, int OC, 
 // launch_tail_wgrad_finalize(wpartials, <returned block count>, dW).
 int launch_tail_join_bwd_reduce(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                                 const float* ms1, const float* mb1, const void* y0, const void* y1, float* partials, hipStream_t s,
-                                float* wpartials) {
+                                float* wpartials, int f8in) {
   return launch_tail_join<false>(dt, d_raw, w, OC, N, H, W, ms, mb, ms1, mb1, y0, nullptr, nullptr, nullptr, nullptr, y1, nullptr, nullptr, nullptr,
-                                 nullptr, partials, wpartials, s);
+                                 nullptr, partials, wpartials, s, f8in);
 }
 
 int launch_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,

@@ -215,8 +215,11 @@ struct TailFwdStreamArgs {
   int N, H, HS, nunits;
 };
 
+// F8I: y2 / ys are e4m3 bytes (16 per pixel): a lane stages one whole pixel per row instead of two half pixels
+template <bool F8I>
 __global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamArgs a) {
   constexpr int KS = 3, W = 64, CB = 32;                                   // bytes per pixel (16 channels of bf16)
+  constexpr int NC = F8I ? 16 : 8;                                         // channels a lane stages
   constexpr int WL = W + 2, ROWB = WL * CB, NSLOT = KS + 1, WAVE_LDS = NSLOT * ROWB, NPRIME = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
@@ -239,11 +242,11 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamAr
     }
   const float bias = a.bias ? a.bias[0] : 0.f;
   // join coefficients of the 8 channels this lane stages (vector lane + 64k of a row: channels 8 * (lane & 1) ..)
-  float c2s[8], c2b[8], css[8];
+  float c2s[NC], c2b[NC], css[NC];
   {
-    const int c = (lane & 1) * 8;
+    const int c = F8I ? 0 : (lane & 1) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { c2s[j] = a.s2[c + j]; c2b[j] = a.b2[c + j] + a.bs[c + j]; css[j] = a.ss[c + j]; }
+    for (int j = 0; j < NC; ++j) { c2s[j] = a.s2[c + j]; c2b[j] = a.b2[c + j] + a.bs[c + j]; css[j] = a.ss[c + j]; }
   }
   float st1 = 0.f, st2 = 0.f;
   const int nblk = gridDim.x;
@@ -260,10 +263,10 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamAr
     const int n = u / nstrips, oh0 = (u - n * nstrips) * a.HS;
     const int row = oh0 + q - NPRIME + 1;                                   // the row arriving at step q
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < (F8I ? 1 : 2); ++k) {
       v2[k] = Vec16{{0, 0, 0, 0}}; vs[k] = Vec16{{0, 0, 0, 0}};
       if (row >= 0 && row < a.H) {
-        const long off = (((long)n * a.H + row) * W) * CB + (lane + 64 * k) * 16;
+        const long off = (((long)n * a.H + row) * W) * (F8I ? 16 : CB) + (lane + 64 * k) * 16;
         v2[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.y2) + off);
         vs[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.ys) + off);
       }
@@ -273,14 +276,25 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamAr
     const int n = u / nstrips, oh0 = (u - n * nstrips) * a.HS;
     const int row = oh0 + q - NPRIME + 1;
     const bool in = row >= 0 && row < a.H;
+    if constexpr (F8I) {
+      float f2[16], fs[16];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      float f2[8], fs[8];
-      Elem<bf16_t>::unpack(v2[k], f2);
-      Elem<bf16_t>::unpack(vs[k], fs);
+      for (int q4 = 0; q4 < 4; ++q4) { unpack4_fp8(v2[0].w[q4], f2 + 4 * q4); unpack4_fp8(vs[0].w[q4], fs + 4 * q4); }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f2[j] = in ? fmaxf(f2[j] * c2s[j] + c2b[j] + fs[j] * css[j], 0.f) : 0.f;
-      *reinterpret_cast<Vec16*>(ring + ((row + 4 * NSLOT) % NSLOT) * ROWB + CB + (lane + 64 * k) * 16) = Elem<bf16_t>::pack(f2);
+      for (int j = 0; j < 16; ++j) f2[j] = in ? fmaxf(f2[j] * c2s[j] + c2b[j] + fs[j] * css[j], 0.f) : 0.f;
+      char* dstp = ring + ((row + 4 * NSLOT) % NSLOT) * ROWB + CB + lane * 32;
+      *reinterpret_cast<Vec16*>(dstp) = Elem<bf16_t>::pack(f2);
+      *reinterpret_cast<Vec16*>(dstp + 16) = Elem<bf16_t>::pack(f2 + 8);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float f2[8], fs[8];
+        Elem<bf16_t>::unpack(v2[k], f2);
+        Elem<bf16_t>::unpack(vs[k], fs);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f2[j] = in ? fmaxf(f2[j] * c2s[j] + c2b[j] + fs[j] * css[j], 0.f) : 0.f;
+        *reinterpret_cast<Vec16*>(ring + ((row + 4 * NSLOT) % NSLOT) * ROWB + CB + (lane + 64 * k) * 16) = Elem<bf16_t>::pack(f2);
+      }
     }
     (void)n;
   };
@@ -345,10 +359,12 @@ struct ConvT4StreamArgs {
   int N, Hi, HS, nunits;
 };
 
-template <int WIN, bool PRO>
+// F8O (fp8 mode, the 32x32 -> 64x64 layers): the output leaves as e4m3 bytes, 16 per pixel (the statistics are still those of the f32 results)
+template <int WIN, bool PRO, bool F8O = false>
 __global__ __launch_bounds__(256, 3) void convT4_stream_kernel(ConvT4StreamArgs a) {
   constexpr int CB = 32, WL = WIN + 2, ROWB = WL * CB, NSLOT = 4, NPRIME = 2;
-  constexpr int OROWB = 2 * WIN * CB;                                       // one output row
+  constexpr int CBO = F8O ? 16 : 32;                                        // bytes per output pixel
+  constexpr int OROWB = 2 * WIN * CBO;                                      // one output row
   constexpr int WAVE_LDS = NSLOT * ROWB + OROWB;
   constexpr int XV = (WIN * CB + 1023) / 1024;                              // input-row vectors per lane (WIN = 32: 1; 16: 1, half the lanes)
   constexpr int NPT = WIN / 16;
@@ -442,13 +458,17 @@ __global__ __launch_bounds__(256, 3) void convT4_stream_kernel(ConvT4StreamArgs 
           for (int pt = 0; pt < NPT; ++pt) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { st1[j] += acc[pt][j]; st2[j] += acc[pt][j] * acc[pt][j]; }
-            uint2 o;
-            o.x = pack2_bf16(acc[pt][0], acc[pt][1]); o.y = pack2_bf16(acc[pt][2], acc[pt][3]);
-            *reinterpret_cast<uint2*>(orow + (2 * (16 * pt + r) + pw) * CB + gq * 8) = o;
+            if constexpr (F8O) {
+              *reinterpret_cast<uint32_t*>(orow + (2 * (16 * pt + r) + pw) * CBO + gq * 4) = pack4_fp8(acc[pt][0], acc[pt][1], acc[pt][2], acc[pt][3]);
+            } else {
+              uint2 o;
+              o.x = pack2_bf16(acc[pt][0], acc[pt][1]); o.y = pack2_bf16(acc[pt][2], acc[pt][3]);
+              *reinterpret_cast<uint2*>(orow + (2 * (16 * pt + r) + pw) * CB + gq * 8) = o;
+            }
           }
         }
         // the finished output row 2*iq + ph leaves as 16 bytes per lane
-        char* dst = reinterpret_cast<char*>(a.y) + (((long)n * (2 * a.Hi) + 2 * iq + ph) * (2 * WIN)) * CB;
+        char* dst = reinterpret_cast<char*>(a.y) + (((long)n * (2 * a.Hi) + 2 * iq + ph) * (2 * WIN)) * CBO;
 #pragma unroll
         for (int k = 0; k < OROWB / 1024; ++k) *reinterpret_cast<Vec16*>(dst + (lane + 64 * k) * 16) = *reinterpret_cast<const Vec16*>(orow + (lane + 64 * k) * 16);
       }
@@ -472,7 +492,7 @@ bool convT4_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, i
 }
 // y [N][2H][2H][16] = conv_transpose2d(x [N][H][H][16]) with the packed per-phase "up" weights; returns stats rows (> 0) or an error
 int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const float* pro_scale, const float* pro_shift, int pro_relu, float* stats,
-                         int N, int Hin, hipStream_t s) {
+                         int N, int Hin, hipStream_t s, int f8out) {
   if (!convT4_stream_ok(dt, 16, 16, 4, 2, 1, Hin, Hin)) { set_error("convT4_stream: bf16, 16 -> 16 channels, k4 s2 p1, 16x16 or 32x32 input"); return MMVAE_ERR_UNSUPPORTED; }
   ConvT4StreamArgs a; memset(&a, 0, sizeof(a));
   a.x = x; a.w = w_up; a.y = y; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu; a.stats = stats;
@@ -483,9 +503,11 @@ int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const
   while (gx > 8 && (long)gx * 4 > a.nunits) gx -= 8;
   const bool pro = pro_scale != nullptr;
   const size_t lds = 1024 + 4 * (size_t)(4 * (Hin + 2) * 32 + 2 * Hin * 32);
-  if (Hin == 32) { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<32, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<32, false>), dim3(gx), dim3(256), lds, s, a); }
+  if (f8out && Hin != 32) { set_error("convT4_stream: e4m3 output only for the 32x32 -> 64x64 layers"); return MMVAE_ERR_UNSUPPORTED; }
+  if (f8out) { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<32, true, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<32, false, true>), dim3(gx), dim3(256), lds, s, a); }
+  else if (Hin == 32) { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<32, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<32, false>), dim3(gx), dim3(256), lds, s, a); }
   else { if (pro) hipLaunchKernelGGL((convT4_stream_kernel<16, true>), dim3(gx), dim3(256), lds, s, a); else hipLaunchKernelGGL((convT4_stream_kernel<16, false>), dim3(gx), dim3(256), lds, s, a); }
-  note_launch_bytes((double)N * 16 * 2.0 * 5.0 * Hin * Hin);                 // x + y = (1 + 4) Hin^2 pixels of 16 bf16 channels
+  note_launch_bytes((double)N * 16 * (2.0 + (f8out ? 4.0 : 8.0)) * Hin * Hin);   // x + y = (1 + 4) Hin^2 pixels of 16 channels (bf16; y e4m3 with f8out)
   const int rc = check_launch("convT4_stream");
   return rc ? rc : gx;
 }
@@ -496,7 +518,7 @@ bool tail_fwd_stream_ok(int dt, int OC, int H, int W) {
 }
 // returns the number of partial rows [rows][2][1] (> 0) or an error
 int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs, const float* w,
-                           const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s) {
+                           const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s, int f8in) {
   if (!tail_fwd_stream_ok(dt, 1, H, W)) { set_error("tail_fwd_stream: bf16, one output plane, 64x64"); return MMVAE_ERR_UNSUPPORTED; }
   TailFwdStreamArgs a; memset(&a, 0, sizeof(a));
   a.y2 = y2; a.ys = ys; a.s2 = s2; a.b2 = b2; a.ss = ss; a.bs = bs; a.w = w; a.bias = bias; a.r_raw = r_raw; a.stats = stats;
@@ -505,8 +527,9 @@ int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float*
   int gx = 768;                                              // rows of `stats` <= N: the entry point's contract is an [N][2] buffer
   while (gx > 1 && (long)gx * 4 > a.nunits) gx -= gx > 8 ? 8 : 1;
   const size_t lds = 64 + 4 * (size_t)(4 * 66 * 32);
-  hipLaunchKernelGGL(tail_fwd_stream_kernel, dim3(gx), dim3(256), lds, s, a);
-  note_launch_bytes((double)N * H * W * (2 * 16 * 2.0 + 4.0));
+  if (f8in) hipLaunchKernelGGL(tail_fwd_stream_kernel<true>, dim3(gx), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(tail_fwd_stream_kernel<false>, dim3(gx), dim3(256), lds, s, a);
+  note_launch_bytes((double)N * H * W * (2 * 16 * (f8in ? 1.0 : 2.0) + 4.0));
   const int rc = check_launch("tail_fwd_stream");
   return rc ? rc : gx;
 }

@@ -53,7 +53,8 @@ struct JoinBwdArgs {
 // (the one-wave-per-strip form needed the whole 512-register file and ran at 2.3 TB/s).  Two block barriers per step order the
 // pair's LDS traffic: [d_raw rows, P rows] -> barrier -> [produce] -> barrier -> [consume]; the loads of the next step are in flight
 // during the consume phase.  A block = two pairs; every pair runs the same number of steps (idle ones past its last unit).
-template <bool PRO_X, int PAIRS>
+// F8I: y2 / ys are e4m3 bytes (fp8 mode's storage of these two tensors): a lane's 4 channels of a pixel are one dword
+template <bool PRO_X, int PAIRS, bool F8I = false>
 __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwdArgs a) {
   constexpr int KS = 4, S = 2, PAD = 1, WP = 32, Wg = 64;
   constexpr int WL = S * (WP - 1) + KS;                    // 66 ring columns: -1 .. 64
@@ -163,8 +164,13 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
 #pragma unroll
       for (int pt = 0; pt < 4; ++pt) {
         const long e = (((long)n * a.Hg + (ok ? row : 0)) * Wg + 16 * pt + r) * 16 + 4 * gq;
-        q2[pt] = ok ? load_nt(reinterpret_cast<const uint2*>(Y2 + e)) : make_uint2(0, 0);
-        qs[pt] = ok ? load_nt(reinterpret_cast<const uint2*>(YS + e)) : make_uint2(0, 0);
+        if constexpr (F8I) {
+          q2[pt] = make_uint2(ok ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(Y2) + e)) : 0u, 0u);
+          qs[pt] = make_uint2(ok ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(YS) + e)) : 0u, 0u);
+        } else {
+          q2[pt] = ok ? load_nt(reinterpret_cast<const uint2*>(Y2 + e)) : make_uint2(0, 0);
+          qs[pt] = ok ? load_nt(reinterpret_cast<const uint2*>(YS + e)) : make_uint2(0, 0);
+        }
       }
     }
     // d_raw rows (wave 0): a dy row needs its neighbours above and below.  Priming: rows top - 2 .. top + 1 (four rows, one float4
@@ -228,8 +234,9 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
       }
       const f32x4 g = mma_bf16(wA, bf, (f32x4){0.f, 0.f, 0.f, 0.f});
       const uint2 v2 = q2[pt], vs = qs[pt];
-      const float f0[4] = {__uint_as_float(v2.x << 16), __uint_as_float(v2.x & 0xffff0000u), __uint_as_float(v2.y << 16), __uint_as_float(v2.y & 0xffff0000u)};
-      const float f1[4] = {__uint_as_float(vs.x << 16), __uint_as_float(vs.x & 0xffff0000u), __uint_as_float(vs.y << 16), __uint_as_float(vs.y & 0xffff0000u)};
+      float f0[4], f1[4];
+      if constexpr (F8I) { unpack4_fp8(v2.x, f0); unpack4_fp8(vs.x, f1); }
+      else { unpack4_bf16(v2, f0); unpack4_bf16(vs, f1); }
       float r0[4], r1[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -367,11 +374,16 @@ int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s) {
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { set_error("join_bwd_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
     attr_set = true;
   }
-  note_launch_bytes((double)L.N * (2.0 * 64 * 64 * 16 * 2 + 64 * 64 * 4.0 + 4.0 * 32 * 32 * 16 * 2));   // y2, ys, d_raw; y1, xin, d_a1, g_in
-  if (L.pxs) hipLaunchKernelGGL((join_bwd_stream_kernel<true, 2>), dim3(gx), dim3(256), lds, s, a);
+  note_launch_bytes((double)L.N * (2.0 * 64 * 64 * 16 * (L.f8in ? 1 : 2) + 64 * 64 * 4.0 + 4.0 * 32 * 32 * 16 * 2));   // y2, ys, d_raw; y1, xin, d_a1, g_in
+  if (L.f8in) {
+    if (L.pxs) hipLaunchKernelGGL((join_bwd_stream_kernel<true, 2, true>), dim3(gx), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((join_bwd_stream_kernel<false, 2, true>), dim3(gx), dim3(256), lds, s, a);
+  } else if (L.pxs) hipLaunchKernelGGL((join_bwd_stream_kernel<true, 2>), dim3(gx), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((join_bwd_stream_kernel<false, 2>), dim3(gx), dim3(256), lds, s, a);
   const int rc = check_launch("join_bwd_stream");
   return rc ? rc : gx;

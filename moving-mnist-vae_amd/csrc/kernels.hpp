@@ -84,6 +84,7 @@ struct JoinBwdLaunch {
   const void* y1; const float* p1s; const float* p1b; const void* wd2; void* da1; float* part2; float* bn_part;   // main path (conv2)
   const void* xin; const float* pxs; const float* pxb; const void* wds; void* gin; float* parts;                  // shortcut (upsample)
   int N;
+  int f8in = 0;            // y2 / ys are e4m3 bytes (16 per pixel): fp8 mode's storage of these two tensors
 };
 bool join_bwd_stream_ok(int dt, int OC, int C, int Hp, int Hg);
 int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s);    // returns blocks = partial images per conv = rows of bn_part
@@ -216,11 +217,11 @@ int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const 
 // ConvTranspose2d(16 -> 16, k4 s2 p1) forward on 16x16 / 32x32 inputs as a per-wave stream (conv_fstream.hip)
 bool convT4_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win);
 int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const float* pro_scale, const float* pro_shift, int pro_relu, float* stats,
-                         int N, int Hin, hipStream_t s);
+                         int N, int Hin, hipStream_t s, int f8out = 0);    // f8out: y leaves as e4m3 bytes (32x32 inputs only)
 // last up-block join + one-plane tail conv as a per-wave MFMA stream (conv_fstream.hip; bf16, 64x64): returns stats rows or an error
 bool tail_fwd_stream_ok(int dt, int OC, int H, int W);
 int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs, const float* w,
-                           const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s);
+                           const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s, int f8in = 0);
 // stem forward as a per-wave stream (bf16; stem_bwd.hip): returns stats rows (> 0) or an error
 bool stem_fwd_stream_ok(int dt, int S);
 int launch_stem_fwd_stream(int dt, const void* x, const float* w, void* y, float* stats, int N, int S, hipStream_t s);
@@ -285,7 +286,7 @@ int launch_bn_bwd_apply(int dt, const void* dout, const void* out, const float* 
 bool tail_join_fusable(int dt, int OC, int N, int H, int W);
 int launch_tail_join_bwd_reduce(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                                 const float* ms1, const float* mb1, const void* y0, const void* y1, float* partials, hipStream_t s,
-                                float* wpartials = nullptr);
+                                float* wpartials = nullptr, int f8in = 0);
 int launch_tail_wgrad_finalize(const float* wpartials, int nparts, float* dW, hipStream_t s);
 int launch_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                                const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,

@@ -52,6 +52,22 @@ __device__ __forceinline__ uint2 pack8_fp8(const float* f) {
   return o;
 }
 
+// e4m3 STORAGE of the two largest activations in fp8 mode (decoder.uplayer5's branch outputs): 4 channels of a pixel <-> one dword
+__device__ __forceinline__ uint32_t pack4_fp8(float f0, float f1, float f2, float f3) {
+  uint32_t o = 0;
+  o = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f0, -448.f), 448.f), fminf(fmaxf(f1, -448.f), 448.f), o, false);
+  o = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f2, -448.f), 448.f), fminf(fmaxf(f3, -448.f), 448.f), o, true);
+  return o;
+}
+__device__ __forceinline__ void unpack4_fp8(uint32_t v, float* f) {
+  const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(v, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(v, true);
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+}
+// 4 bf16 channels (8 bytes) of a pixel
+__device__ __forceinline__ void unpack4_bf16(uint2 v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u); f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
 // 8 consecutive output channels of one pixel
 template <typename TO> __device__ __forceinline__ void dstore8(TO* p, const float* v, bool acc);
 template <> __device__ __forceinline__ void dstore8<float>(float* p, const float* v, bool acc) {

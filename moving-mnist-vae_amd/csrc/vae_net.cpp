@@ -142,6 +142,19 @@ Net::Net(const NetCfg& c) : cfg(c) {
     }
   }
   Sd = H;
+  // fp8 mode: the two largest activations of the step (the last up-block's branch outputs at 64x64: 671 MB each in bf16 at 5120 frames, written
+  // once and read three times) are STORED as e4m3 bytes where the four stream kernels that touch them run (convT4_stream -> tail_fwd_stream,
+  // tail_reduce_mfma, join_bwd_stream).  A static weight scale of 16 puts their values mid-range; the BatchNorms behind absorb it exactly
+  // (the same mechanism as an fp8 layer's weight scale).
+  if (cfg.fp8 && !dec.empty()) {
+    Block& L = dec.back();
+    static const bool env = [] { const char* e = getenv("MMVAE_FP8_STORE"); return !(e && e[0] == '0'); }();
+    if (env && !L.identity && L.C == 16 && L.Cin == 16 && L.Hin == 32 && Sd == 64 && c.out_ch == 1 && convT4_stream_ok(DT_BF16, 16, 16, 4, 2, 1, 32, 32) &&
+        tail_fwd_stream_ok(DT_BF16, 1, 64, 64) && join_bwd_stream_ok(DT_BF16, 1, 16, 32, 64)) {
+      store8 = true;
+      L.c2.wscale = 16.f; L.cs.wscale = 16.f;
+    }
+  }
   settle_fp8(dstem);
   for (Block& B : enc) { settle_fp8(B.c1); settle_fp8(B.c2); settle_fp8(B.cs); }
   for (Block& B : dec) { settle_fp8(B.c1); settle_fp8(B.c2); settle_fp8(B.cs); }
@@ -826,7 +839,7 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
       hipStream_t ss = fork ? wgrad_stream(s) : s;
       if (!B.cs.fp8 && convT4_stream_ok(dt(), B.cs.D0, B.cs.D1, B.cs.k, B.cs.s, B.cs.p, B.Hin, B.Win))
         np = launch_convT4_stream(dt(), xin, base + plan_.packed + B.cs.packU * (long)esz(), base + B.ys, xs, xb, 1, stats ? stats + kPartialFloats : nullptr,
-                                  N, B.Hin, ss);
+                                  N, B.Hin, ss, (store8 && i == nd - 1) ? 1 : 0);
       else
         np = run_up(B.cs, base, N, xin, B.Hin, B.Win, base + B.ys, B.Hout, B.Wout, xs, xb, 1, stats ? stats + kPartialFloats : nullptr, 0, ss);
       MM_TRY(np);
@@ -840,13 +853,14 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     else
       if (!B.c2.fp8 && convT4_stream_ok(dt(), B.c2.D0, B.c2.D1, B.c2.k, B.c2.s, B.c2.p, B.Hin, B.Win))   // per-wave stream (conv_fstream.hip)
         np = launch_convT4_stream(dt(), base + B.y1, base + plan_.packed + B.c2.packU * (long)esz(), base + B.y2, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
-                                  stats, N, B.Hin, s);
+                                  stats, N, B.Hin, s, (store8 && i == nd - 1) ? 1 : 0);
       else
         np = run_up(B.c2, base, N, base + B.y1, B.Hin, B.Win, base + B.y2, B.Hout, B.Wout, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, stats, 0, s);
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b2, params, bnbuf, nbt, base, np, cnt, s, 0, B.c2.wscale) : bn_eval(B.b2, params, bnbuf, base, s, B.c2.wscale));
     if (fork) MM_TRY(side_join(s));
     if (i == nd - 1 && tail_fwd_fused()) break;     // the join of the last block happens inside the tail conv kernel
+    if (i == nd - 1 && store8) { set_error("fp8 storage of the last up-block needs the fused tail kernels (MMVAE_TAIL_FWD_FUSED / MMVAE_TAIL_FUSED)"); return MMVAE_ERR_UNSUPPORTED; }
     MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), B.identity ? xin : base + B.ys,
                            B.identity ? ones(base) : bnf(B.bs, base, 2), B.identity ? zeros(base) : bnf(B.bs, base, 3), base + B.out,
                            (long)N * B.Hout * B.Wout, B.C, s));
@@ -858,7 +872,8 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     const Block& B = dec.back();
     if (tail_fwd_stream_ok(dt(), cfg.out_ch, Sd, Sd))
       np = launch_tail_fwd_stream(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
-                                  params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
+                                  params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s, store8 ? 1 : 0);
+    else if (store8) { set_error("fp8 storage of the last up-block needs tail_fwd_stream"); return MMVAE_ERR_UNSUPPORTED; }
     else
       np = launch_tail_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
                                 params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s);
@@ -919,6 +934,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   // forward did not store the joined activation: the weight gradient recomputes it, inside the join-backward reduce pass (below)
   // or, MMVAE_TAIL_WGRAD_IN_REDUCE=0, in its own kernel on the side stream
   const bool tail_wg_in_reduce = tail_fwd_fused() && tail_fused && tail_wg_env;
+  if (store8 && !tail_wg_in_reduce) { set_error("fp8 storage of the last up-block needs the fused tail backward"); return MMVAE_ERR_UNSUPPORTED; }
   if (tail_wg_in_reduce) {
   } else if (tail_fwd_fused()) {
     const Block& B = dec.back();
@@ -974,7 +990,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     const long dyso = B.identity ? P.g[cur ^ 1] : P.dys[ds];
     if (from_tail) {
       np = launch_tail_join_bwd_reduce(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
-                                       bnf(B.bs, base, 3), base + B.y2, base + B.ys, part, s, tail_wg_in_reduce ? wscratch_ : nullptr);
+                                       bnf(B.bs, base, 3), base + B.y2, base + B.ys, part, s, tail_wg_in_reduce ? wscratch_ : nullptr, store8 ? 1 : 0);
       if (tail_wg_in_reduce && np > 0) {
         MM_TRY(side_fork(s));
         MM_TRY(launch_tail_wgrad_finalize(wscratch_, np, grads + tail.off, wgrad_stream(s)));
@@ -998,7 +1014,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       L.wd2 = base + plan_.packed + B.c2.packD * (long)esz(); L.da1 = base + P.da1; L.part2 = ws2; L.bn_part = part;
       L.xin = xin; L.pxs = xs; L.pxb = xb; L.wds = base + plan_.packed + B.cs.packD * (long)esz(); L.gin = base + P.g[cur ^ 1];
       L.parts = ws2 + 1024L * 4096;                        // (at most 1024 blocks, one [16][16][16] partial image per conv each)
-      L.N = N;
+      L.N = N; L.f8in = store8 ? 1 : 0;
       const int nb = launch_join_bwd_stream(L, s);
       MM_TRY(nb);
       auto reduce16 = [&](const float* parts, int nparts, const ConvW& w, int ntaps) {
@@ -1028,6 +1044,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       cur ^= 1;
       continue;
     }
+    if (store8 && i == nd - 1) { set_error("fp8 storage of the last up-block needs join_bwd_stream"); return MMVAE_ERR_UNSUPPORTED; }
     if (from_tail)
       MM_TRY(launch_tail_join_bwd_apply(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
                                         bnf(B.bs, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5), bnf(B.b2, base, 6), base + P.dy2[ds],

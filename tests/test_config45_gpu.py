@@ -106,7 +106,7 @@ def test_full_size_gradients_against_f32(name, oracle):
             rows.append((k, rel, cos, samp))
             if not (rel <= rel_max and cos >= cos_min):
                 bad[k] = ("abs", rel, cos)
-            elif rel > ratio_max * samp:
+            elif rel > 1e-3 and rel > ratio_max * samp:      # (a tensor both modes agree on to 1e-3 has no rounding noise to bound)
                 bad[k] = ("vs sampling noise", rel, samp)
         print(f"\n{name}, N={N}, {tag}: {dt} vs f32 gradients per tensor (rel-L2, cosine) | sampling noise of the f32 gradient (rel-L2)")
         for k, rel, cos, samp in rows:
