@@ -62,7 +62,7 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
   constexpr int NSLOT = 4;                                 // the four dy rows a P row multiplies; the two new ones replace the two oldest
   constexpr int DP = 68;                                   // d_raw ring pitch (floats): column c at index c + 1, zero halo at 0 and 65
   constexpr int NT = 16;
-  constexpr int PAIR_LDS = 2 * NSLOT * ROWB + 3 * 1024 + 4 * DP * 4;
+  constexpr int PAIR_LDS = 2 * NSLOT * ROWB + 3 * 1024 + 2 * 4 * DP * 4;
   constexpr int WDB = 2 * (NT / 2) * 1024;                 // the two convs' data-gradient A fragments
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
   char* prowA = ringB + NSLOT * ROWB;                      // relu(bn1(y1)) row
   char* rawA = prowA + 1024;                               // y1 row as stored (bn1 backward sums)
   char* prowB = rawA + 1024;                               // block-input row
-  float* dring = reinterpret_cast<float*>(prowB + 1024);   // [4][DP] d_raw rows
+  float* dring = reinterpret_cast<float*>(prowB + 1024);   // [hi, lo][4][DP] d_raw rows, split ONCE on the way in: hi = the value rounded to bf16
+                                                           // (as an f32), lo = d - hi; a B fragment is then four v_perm of upper halves
   const bool odd = gq & 1, lo_half = gq >= 2;
 
   // ---- zero: ring border columns, the d ring (halo columns stay zero for the kernel's lifetime) -- each wave its half
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
     for (int i = lane; i < ((WL - PAD) * 32 - Wg * 32) / 16; i += 64)
       reinterpret_cast<Vec16*>(ringA + sl * ROWB + PAD * 32 + Wg * 32)[i] = Vec16{{0, 0, 0, 0}};
   }
-  if (role == 0) for (int i = lane; i < 4 * DP; i += 64) dring[i] = 0.f;
+  if (role == 0) for (int i = lane; i < 2 * 4 * DP; i += 64) dring[i] = 0.f;
   // ---- block-shared A fragments of the two data gradients: [conv][pair of taps][lane]
   for (int i = t; i < 2 * (NT / 2) * 64; i += 128 * PAIRS) {
     const int ln = i & 63, pr = (i >> 6) % (NT / 2), cv = (i >> 6) / (NT / 2);
@@ -190,7 +191,12 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
       const int row = q == 0 ? top - 2 + (lane >> 4) : top + ((lane >> 4) & 1);
       if (q == 0 || lane < 32) {
         float* dst = dring + ((row + 8) & 3) * DP + (lane & 15) * 4 + 1;
-        dst[0] = dv4[0]; dst[1] = dv4[1]; dst[2] = dv4[2]; dst[3] = dv4[3];
+        const uint32_t h01 = pack2_bf16(dv4[0], dv4[1]), h23 = pack2_bf16(dv4[2], dv4[3]);
+        const float h0 = __uint_as_float(h01 << 16), h1 = __uint_as_float(h01 & 0xffff0000u), h2 = __uint_as_float(h23 << 16), h3 = __uint_as_float(h23 & 0xffff0000u);
+        dst[0] = h0; dst[1] = h1; dst[2] = h2; dst[3] = h3;
+        const uint32_t l01 = pack2_bf16(dv4[0] - h0, dv4[1] - h1), l23 = pack2_bf16(dv4[2] - h2, dv4[3] - h3);      // lo rounded (not cut) to bf16
+        dst[4 * DP] = __uint_as_float(l01 << 16); dst[4 * DP + 1] = __uint_as_float(l01 & 0xffff0000u);
+        dst[4 * DP + 2] = __uint_as_float(l23 << 16); dst[4 * DP + 3] = __uint_as_float(l23 & 0xffff0000u);
       }
     }
     if (q > 0) {
@@ -214,9 +220,18 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
     const int row = top - 1 + role;
     const bool ok = row >= 0 && row < a.Hg;
     const int slot = (row + 8) & 3;
-    const float* d0 = dring + ((row + 8) & 3) * DP;          // d_raw rows `row`, row - 1, row + 1 (ring slots mod 4)
-    const float* dm = dring + ((row + 7) & 3) * DP;
-    const float* dq = dring + ((row + 9) & 3) * DP;
+    const float* dimg = dring + (lo_half ? 4 * DP : 0);      // k = 0..15: hi parts, k = 16..31: lo parts against the same weights
+    const float* d0 = dimg + ((row + 8) & 3) * DP;           // d_raw rows `row`, row - 1, row + 1 (ring slots mod 4)
+    const float* dm = dimg + ((row + 7) & 3) * DP;
+    const float* dq = dimg + ((row + 9) & 3) * DP;
+    if (!ok) {                                               // (wave-uniform) rows outside the image are the convolution's zero padding
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        *reinterpret_cast<uint2*>(ringA + slot * ROWB + (PAD + 16 * pt + r) * 32 + gq * 8) = make_uint2(0u, 0u);
+        *reinterpret_cast<uint2*>(ringB + slot * ROWB + (PAD + 16 * pt + r) * 32 + gq * 8) = make_uint2(0u, 0u);
+      }
+      return;
+    }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int c = 16 * pt + r + 1;                         // ring index of the pixel's column
@@ -224,14 +239,10 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
       float dv[8];
       dv[0] = odd ? dm[c - 1] : dq[c + 1];
       dv[1] = dq[c]; dv[2] = dq[c - 1]; dv[3] = d0[c + 1]; dv[4] = d0[c]; dv[5] = d0[c - 1]; dv[6] = dm[c + 1]; dv[7] = dm[c];
+      // (odd gq: only k-slot 0 = tap 8 meets a non-zero weight in wA; the other seven values are finite and multiply zeros)
       Vec16 bf;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float e0 = (odd && k > 0) ? 0.f : dv[2 * k], e1 = odd ? 0.f : dv[2 * k + 1];
-        const uint32_t hi = pack2_bf16(e0, e1);
-        const uint32_t lo = pack2_bf16(e0 - __uint_as_float(hi << 16), e1 - __uint_as_float(hi & 0xffff0000u));
-        bf.w[k] = lo_half ? lo : hi;
-      }
+      for (int k = 0; k < 4; ++k) bf.w[k] = __builtin_amdgcn_perm(__float_as_uint(dv[2 * k + 1]), __float_as_uint(dv[2 * k]), 0x07060302u);
       const f32x4 g = mma_bf16(wA, bf, (f32x4){0.f, 0.f, 0.f, 0.f});
       const uint2 v2 = q2[pt], vs = qs[pt];
       float f0[4], f1[4];
@@ -242,8 +253,8 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
       for (int j = 0; j < 4; ++j) {
         const float x = (f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]);
         const float gg = x > 0.f ? g[j] : 0.f;
-        r0[j] = ok ? ca0[j] * gg + cb0[j] * f0[j] + cc0[j] : 0.f;
-        r1[j] = ok ? ca1[j] * gg + cb1[j] * f1[j] + cc1[j] : 0.f;
+        r0[j] = ca0[j] * gg + cb0[j] * f0[j] + cc0[j];
+        r1[j] = ca1[j] * gg + cb1[j] * f1[j] + cc1[j];
       }
       *reinterpret_cast<uint2*>(ringA + slot * ROWB + (PAD + 16 * pt + r) * 32 + gq * 8) = make_uint2(pack2_bf16(r0[0], r0[1]), pack2_bf16(r0[2], r0[3]));
       *reinterpret_cast<uint2*>(ringB + slot * ROWB + (PAD + 16 * pt + r) * 32 + gq * 8) = make_uint2(pack2_bf16(r1[0], r1[1]), pack2_bf16(r1[2], r1[3]));
@@ -368,7 +379,7 @@ int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s) {
   constexpr int pairs = 2;
   int gx = 512;                                             // two blocks of two wave pairs per CU (LDS: 58 KB each)
   while (gx > 8 && (long)gx * pairs > a.nunits) gx -= 8;
-  constexpr size_t lds = 2 * 8 * 1024 + pairs * (size_t)(2 * 4 * 66 * 32 + 3 * 1024 + 4 * 68 * 4);
+  constexpr size_t lds = 2 * 8 * 1024 + pairs * (size_t)(2 * 4 * 66 * 32 + 3 * 1024 + 2 * 4 * 68 * 4);
   static_assert(lds >= 2 * 16 * 256 * 4 + 512, "the flush images alias the rings");
   static bool attr_set = false;
   if (!attr_set) {
