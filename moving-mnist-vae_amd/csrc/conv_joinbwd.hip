@@ -376,26 +376,29 @@ int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s) {
   if (!L.p1s || !L.p1b) { set_error("join_bwd_stream: conv2's input needs bn1's scale / shift"); return MMVAE_ERR_ARG; }
   // measured (config 2, ms per step): two pairs per block x 512 blocks 7.17; 384 blocks 7.34; 768 blocks 7.24; one pair per block
   // (128 threads, 1024 blocks) 9.8 -- its register cap spills the accumulators
+  // ... (round 3, after the producer's instruction diet: one pair per block x 1024 blocks, four blocks per CU by LDS, 7.006 / 7.007 against
+  // 6.990 / 7.041 -- the block barrier that couples the two pairs is not the limit; the kernel is bound by its instruction issue, not by
+  // memory: e4m3 storage of y2 / ys (fp8 mode, 1.4 GB fewer bytes) leaves its 600 us unchanged)
   constexpr int pairs = 2;
-  int gx = 512;                                             // two blocks of two wave pairs per CU (LDS: 58 KB each)
+  int gx = 512;                                             // two blocks of two wave pairs per CU (LDS: 59 KB each)
   while (gx > 8 && (long)gx * pairs > a.nunits) gx -= 8;
   constexpr size_t lds = 2 * 8 * 1024 + pairs * (size_t)(2 * 4 * 66 * 32 + 3 * 1024 + 2 * 4 * 68 * 4);
   static_assert(lds >= 2 * 16 * 256 * 4 + 512, "the flush images alias the rings");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { set_error("join_bwd_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
-    attr_set = true;
-  }
   note_launch_bytes((double)L.N * (2.0 * 64 * 64 * 16 * (L.f8in ? 1 : 2) + 64 * 64 * 4.0 + 4.0 * 32 * 32 * 16 * 2));   // y2, ys, d_raw; y1, xin, d_a1, g_in
-  if (L.f8in) {
-    if (L.pxs) hipLaunchKernelGGL((join_bwd_stream_kernel<true, 2, true>), dim3(gx), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((join_bwd_stream_kernel<false, 2, true>), dim3(gx), dim3(256), lds, s, a);
-  } else if (L.pxs) hipLaunchKernelGGL((join_bwd_stream_kernel<true, 2>), dim3(gx), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((join_bwd_stream_kernel<false, 2>), dim3(gx), dim3(256), lds, s, a);
+#define MMVAE_JB(PX, PR, F8)                                                                                                        \
+  do {                                                                                                                               \
+    static bool attr_set = false;                                                                                                    \
+    if (!attr_set) {                                                                                                                 \
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&join_bwd_stream_kernel<PX, PR, F8>),                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+      if (e != hipSuccess) { set_error("join_bwd_stream: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }    \
+      attr_set = true;                                                                                                               \
+    }                                                                                                                                \
+    hipLaunchKernelGGL((join_bwd_stream_kernel<PX, PR, F8>), dim3(gx), dim3(128 * PR), lds, s, a);                                   \
+  } while (0)
+  if (L.f8in) { if (L.pxs) MMVAE_JB(true, 2, true); else MMVAE_JB(false, 2, true); }
+  else { if (L.pxs) MMVAE_JB(true, 2, false); else MMVAE_JB(false, 2, false); }
+#undef MMVAE_JB
   const int rc = check_launch("join_bwd_stream");
   return rc ? rc : gx;
 }
