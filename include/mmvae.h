@@ -44,10 +44,15 @@ extern "C" {
 #define MMVAE_FP8 2     /* network handle only (BASELINE configs[4]): bf16 storage, but the forward convolutions of the deep layers (channel
                            counts that are multiples of 64, every one followed by a BatchNorm) run on v_mfma_f32_16x16x32_fp8_fp8: OCP e4m3
                            weights (static power-of-two scale per layer, absorbed exactly by the BatchNorm) x e4m3 activations (quantised
-                           behind the fused BN+ReLU), f32 accumulation and statistics; the backward pass stays bf16 (straight-through) */
+                           behind the fused BN+ReLU), f32 accumulation and statistics; the backward pass stays bf16 (straight-through).
+                           Where the 64x64 last up-block runs on the stream kernels its two branch outputs (the largest tensors of the
+                           step) are STORED as e4m3 bytes with a static scale of 16 the BatchNorms behind absorb */
 
 /* Version of this header's signatures.  2: mmvae_conv2d_wgrad gained the caller-owned `scratch` argument (before `stream`);
- * a binding built against version 1 must not call version 2 (check mmvae_abi_version() == MMVAE_ABI_VERSION at load time). */
+ * 3: mmvae_convT_bwd_fused gained `dw2`, the weight-gradient entry points REQUIRE the scratch (partial images, fixed-order reduce: no
+ * float atomics), new entries (stage_labels, encoder_fwd_staged, decoder_bwd_gauss, upblock / conv1x1_bwd_fused, set_sync_bn_comm2,
+ * pixelcnn_*); in_channels 1..4.  A binding built against another version must not call this one (check mmvae_abi_version() ==
+ * MMVAE_ABI_VERSION at load time). */
 #define MMVAE_ABI_VERSION 3
 MMVAE_API int mmvae_abi_version(void);
 MMVAE_API const char* mmvae_last_error(void);          /* host string, valid until the next failing call on this thread */

@@ -133,11 +133,12 @@ int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* 
 
 int op_run_wgrad(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                  const void* G, int Hl, int Wl, const float* proG_s, const float* proG_b, int proG_relu, float* dW, hipStream_t s,
-                 float* scratch, float scale) {
+                 float* scratch, float scale, WgradReduceArgs* defer) {
   WgradArgs a; std::memset(&a, 0, sizeof(a));
   const int kk = g.k * g.k;
   if (kk > 25) { set_error("wgrad: k=%d too large", g.k); return MMVAE_ERR_UNSUPPORTED; }
-  a.P = P; a.G = G; a.dW = dW; a.scratch = scratch;
+  if (defer) defer->nparts = 0;
+  a.P = P; a.G = G; a.dW = dW; a.scratch = scratch; a.defer = defer;
   a.proP_scale = proP_s; a.proP_shift = proP_b; a.proP_relu = proP_relu;
   a.proG_scale = proG_s; a.proG_shift = proG_b; a.proG_relu = proG_relu;
   a.N = N; a.Hp = Hs; a.Wp = Ws; a.Ca = g.D0; a.Hg = Hl; a.Wg = Wl; a.Cb = g.D1; a.Cb_valid = g.D1;

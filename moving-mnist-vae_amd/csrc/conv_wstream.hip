@@ -492,6 +492,7 @@ static int wstream_reduce(const WgradArgs& a, int gx, hipStream_t s, bool x2 = f
   u.Ca_valid = a.Ca_valid; u.Cb_valid = a.Cb_valid; u.sA = a.sA; u.sB = a.sB; u.scale = a.scale;
   u.part_stride = (long)a.ntaps * a.Ca * a.Cb + (x2 ? 16L * a.Ca : 0);
   for (int t = 0; t < 25; ++t) u.tap_off[t] = a.tap_off[t];
+  if (a.defer && !x2) { *a.defer = u; return 0; }
   const int rc = launch_wgrad_reduce(u, s);
   if (rc < 0 || !x2 || !dW2) return rc;
   WgradReduceArgs v; memset(&v, 0, sizeof(v));

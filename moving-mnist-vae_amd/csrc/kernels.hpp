@@ -63,6 +63,8 @@ struct WgradArgs {
   float scale;
   int M, pix_per_block;
   int TA16, TB16, TG;      // tile config chosen by the launcher
+  struct WgradReduceArgs* defer;   // optional (stream kernels only): the reduce is NOT launched, its arguments are left here (nparts = 0 when the
+                                   // launch took another kernel and reduced at once) -- the caller launches it later, off the busy phase
 };
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
 int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s);   // conv_wstream.hip: 1 = taken, 0 = not this kernel's shape, <0 error

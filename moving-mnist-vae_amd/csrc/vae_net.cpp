@@ -710,8 +710,16 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
-    MM_TRY(run_wgrad(B.c2, N, base + dy2o, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
-                     bnf(B.b1, base, 3), grads, wsm));
+    // encoder.layer1 (the block the step ends on): conv2's partial images go to the second scratch (idle in this pass) and are reduced
+    // AFTER the block's other weight gradient has been enqueued -- under the stem backward's load a 19 MB reduce takes 120 us instead of
+    // 10, and it sat in front of the last big kernel of the side stream
+    WgradReduceArgs late; late.nparts = 0;
+    if (i == 0 && wsm != s)
+      MM_TRY(op_run_wgrad(dt(), geom(B.c2), N, base + dy2o, B.Hout, B.Wout, nullptr, nullptr, 1, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
+                          bnf(B.b1, base, 3), 1, grads + B.c2.off, wsm, reinterpret_cast<float*>(base + P.wscratch2), B.c2.wscale, &late));
+    else
+      MM_TRY(run_wgrad(B.c2, N, base + dy2o, B.Hout, B.Wout, nullptr, nullptr, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
+                       bnf(B.b1, base, 3), grads, wsm));
     // (encoder.layer1: the shortcut's weight gradient rides on conv1's pass over the block input, below)
     const bool pair = !B.identity && !B.c1.fp8 && !B.cs.fp8 && wgrad_pair_ok(dt(), geom(B.c1), geom(B.cs), B.Hout, B.Hin);
     if (!B.identity && !pair) MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
@@ -733,6 +741,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
       if (!taken) MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     }
     if (!taken) MM_TRY(run_wgrad(B.c1, N, base + dy1o, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
+    if (late.nparts > 0) MM_TRY(launch_wgrad_reduce(late, wsm));
     MM_TRY(side_mark(i));
     if (B.identity)     // d_xin already holds the shortcut's share: the main path's data gradient is added to it
       MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
