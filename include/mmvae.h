@@ -296,6 +296,15 @@ MMVAE_API int mmvae_upblock_bwd_fused(const float* d_raw, const float* tail_weig
 /* conv1 (1x1, 16 -> 16) of the same block, once bn1's sums are final (A1, B1, C1 = its backward coefficients):
  *   dy1 = A1 (d_a1 [bn1(y1) > 0]) + B1 y1 + C1;  g_in += dy1 (x) W1 (in place);  dw_conv1 (16,16,1,1) += dy1^T (x) pro(xin).
  * rows = N * H rows of 32 pixels.  scratch: MMVAE_WGRAD_SCRATCH_BYTES. */
+/* The same block's FORWARD tail: r_raw = decoder.conv2(relu(bn2(conv2(relu(bn1(y1)))) + upsample.1(upsample.0(x_in)))) (model.py:70-85,193) with both
+ * ConvTranspose2d branch outputs recomputed row by row from their 32x32x16 inputs instead of read back (they are still written by
+ * mmvae_conv2d_fwd for the statistics and the backward pass).  bf16 NHWC inputs, f32 weights in PyTorch layout (w2, wu: [16][16][4][4]; tail
+ * weight [1][16][3][3] + bias), s / b pairs = forward scale / shift of the BatchNorms (sx / bx may be NULL: x_in is an activation);
+ * r_raw f32 [N][64][64]; stats (nullable) receives <return value> partial rows [2] = (sum, sum of squares) of r_raw; scratch >= 16 KB. */
+MMVAE_API int mmvae_upblock_tail_fwd(const void* y1, const float* s1, const float* b1, const float* w2, const void* x_in, const float* sx,
+                                     const float* bx, const float* wu, const float* s2, const float* b2, const float* ss, const float* bs,
+                                     const float* tail_weight, const float* tail_bias, float* r_raw, float* stats, int N, void* scratch,
+                                     void* stream);
 MMVAE_API int mmvae_conv1x1_bwd_fused(const void* d_a1, const void* y1, const float* s1, const float* b1, const float* A1, const float* B1,
                             const float* C1, const void* xin, const float* sx, const float* bx, const float* w_conv1, float* dw_conv1,
                             void* g_in, int64_t rows, void* scratch, void* stream);

@@ -445,6 +445,19 @@ int mmvae_upblock_bwd_fused(const float* d_raw, const float* tw, const void* y2,
   }
   return launch_partial_rowsum(L.bn_part, nb, 32, bn1_sums, S(st));
 }
+int mmvae_upblock_tail_fwd(const void* y1, const float* s1, const float* b1, const float* w2, const void* xin, const float* sx, const float* bx,
+                           const float* wu, const float* s2, const float* b2, const float* ss, const float* bs, const float* tw, const float* bias,
+                           float* r_raw, float* stats, int N, void* scratch, void* st) {
+  if (!scratch || !y1 || !s1 || !b1 || !w2 || !xin || !wu || !s2 || !b2 || !ss || !bs || !tw || !r_raw || N < 1 || ((sx != nullptr) != (bx != nullptr))) {
+    set_error("upblock_tail_fwd: bad argument"); return MMVAE_ERR_ARG;
+  }
+  if (!up5_tail_fwd_ok(DT_BF16, 1, 16, 16, 32, 64)) { set_error("upblock_tail_fwd: disabled (MMVAE_TAIL_RECOMPUTE=0)"); return MMVAE_ERR_UNSUPPORTED; }
+  char* sc = static_cast<char*>(scratch);
+  const ConvGeom g = geom_for(1, 16, 16, 4, 2, 1);
+  int rc = op_pack_up(DT_BF16, g, w2, sc, S(st)); if (rc < 0) return rc;
+  rc = op_pack_up(DT_BF16, g, wu, sc + 8192, S(st)); if (rc < 0) return rc;
+  return launch_up5_tail_fwd(y1, s1, b1, sc, xin, sx, bx, sc + 8192, s2, b2, ss, bs, tw, bias, r_raw, stats, N, S(st));
+}
 int mmvae_conv1x1_bwd_fused(const void* da1, const void* y1, const float* s1, const float* b1, const float* A1, const float* B1, const float* C1,
                             const void* xin, const float* sx, const float* bx, const float* w1, float* dw1, void* gin, int64_t rows, void* scratch,
                             void* st) {

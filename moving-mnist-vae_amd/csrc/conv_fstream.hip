@@ -486,6 +486,232 @@ __global__ __launch_bounds__(256, 3) void convT4_stream_kernel(ConvT4StreamArgs 
   if (a.stats && t < 32) a.stats[(long)blockIdx.x * 32 + t] = (sb[t] + sb[32 + t]) + (sb[64 + t] + sb[96 + t]);
 }
 
+// ---------------------------------------------------------------- last up-block: join + tail conv with the branch outputs RECOMPUTED
+// up5_tail_fwd_kernel: tail_fwd_stream_kernel reads the two 64x64x16 branch outputs (1.34 GB at 5120 frames) that convT4_stream_kernel wrote a
+// moment ago; the forward kernels of this block are memory-bound (e4m3 storage of those tensors makes them 28-35 % faster, DESIGN lesson 36).
+// Here a wave keeps rings of the two ConvTranspose2d INPUT rows (32x32x16: 0.34 GB together) and recomputes both branch outputs for the
+// two output rows of an input row exactly like convT4_stream_kernel does (same MFMA sequence, the results rounded to bf16 like the stored
+// tensors), joins them in the D-fragment mapping (lane = 4 channels of one output pixel) into the ring of joined rows the tail conv reads.
+// y2 / ys are still written by convT4_stream_kernel (statistics; the backward pass reads them): this kernel only stops READING them.
+struct Up5TailFwdArgs {
+  const void* y1; const float* p1s; const float* p1b; const void* w2;      // conv2 branch: input (pre-bn1), bn1 scale / shift, packed up weights
+  const void* xin; const float* pxs; const float* pxb; const void* wu;     // upsample branch: block input (+ optional BatchNorm+ReLU), packed up weights
+  const float* s2; const float* b2; const float* ss; const float* bs;      // join coefficients (forward scale / shift of bn2 and of the shortcut's BatchNorm)
+  const float* w; const float* bias; float* r_raw; float* stats;
+  int N, HS, nunits;
+};
+
+template <bool PRO_X>
+__global__ __launch_bounds__(256, 2) void up5_tail_fwd_kernel(Up5TailFwdArgs a) {
+  constexpr int WIN = 32, Hi = 32, W = 64, H = 64, CB = 32;
+  constexpr int IWL = WIN + 2, IROWB = IWL * CB, NSLOT = 4;                // input rings: 4 rows of 34 pixels
+  constexpr int JWL = W + 2, JROWB = JWL * CB;                              // joined ring: 4 rows of 66 pixels
+  constexpr int WAVE_LDS = 2 * NSLOT * IROWB + NSLOT * JROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
+  char* ringA = smem + 64 + wv * WAVE_LDS;                                  // relu(bn1(y1)) rows
+  char* ringX = ringA + NSLOT * IROWB;                                      // block-input rows
+  char* ringJ = ringX + NSLOT * IROWB;                                      // joined rows
+  for (int sl = 0; sl < NSLOT; ++sl) {
+    if (lane < 2) { *reinterpret_cast<Vec16*>(ringA + sl * IROWB + lane * 16) = Vec16{{0, 0, 0, 0}}; *reinterpret_cast<Vec16*>(ringX + sl * IROWB + lane * 16) = Vec16{{0, 0, 0, 0}}; }
+    else if (lane < 4) { *reinterpret_cast<Vec16*>(ringA + sl * IROWB + (IWL - 1) * CB + (lane - 2) * 16) = Vec16{{0, 0, 0, 0}}; *reinterpret_cast<Vec16*>(ringX + sl * IROWB + (IWL - 1) * CB + (lane - 2) * 16) = Vec16{{0, 0, 0, 0}}; }
+    else if (lane < 6) *reinterpret_cast<Vec16*>(ringJ + sl * JROWB + (lane - 4) * 16) = Vec16{{0, 0, 0, 0}};
+    else if (lane < 8) *reinterpret_cast<Vec16*>(ringJ + sl * JROWB + (JWL - 1) * CB + (lane - 6) * 16) = Vec16{{0, 0, 0, 0}};
+  }
+  // ConvTranspose2d A fragments of both branches (as in convT4_stream_kernel): [phase = 2 ph + pw][th]
+  Vec16 w2A[4][2], wuA[4][2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+      w2A[p][th] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.w2) + p * 2048 + r * 128 + th * 64 + gq * 16);
+      wuA[p][th] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.wu) + p * 2048 + r * 128 + th * 64 + gq * 16);
+    }
+  const int dwl[2] = {(gq >> 1) ? -1 : 0, (gq >> 1) ? 0 : 1};
+  // tail conv A fragments (as in tail_fwd_stream_kernel): only output row 0 is real
+  Vec16 wT[3][2];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float f[8];
+      const int kw = 2 * half + (gq >> 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int c = 8 * (gq & 1) + j; f[j] = (r == 0 && kw < 3) ? a.w[c * 9 + kh * 3 + kw] : 0.f; }
+      wT[kh][half] = Elem<bf16_t>::pack(f);
+    }
+  const float bias = a.bias ? a.bias[0] : 0.f;
+  // prologue coefficients of the 8 channels this lane stages per input row; join coefficients of this lane's 4 output channels
+  float p1s[8], p1b[8], pxs[8], pxb[8];
+  {
+    const int c = (lane & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p1s[j] = a.p1s[c + j]; p1b[j] = a.p1b[c + j]; pxs[j] = PRO_X ? a.pxs[c + j] : 1.f; pxb[j] = PRO_X ? a.pxb[c + j] : 0.f; }
+  }
+  float js2[4], jb[4], jss[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int c = 4 * gq + j; js2[j] = a.s2[c]; jb[j] = a.b2[c] + a.bs[c]; jss[j] = a.ss[c]; }
+  float st1 = 0.f, st2 = 0.f;
+  const int nblk = gridDim.x;
+  int u_first, u_step, u_end;
+  if ((nblk & 7) == 0) {
+    const int per = (a.nunits + 7) >> 3;
+    const int lo_u = (blockIdx.x & 7) * per;
+    u_first = lo_u + (blockIdx.x >> 3) * 4 + wv; u_step = (nblk >> 3) * 4; u_end = min(a.nunits, lo_u + per);
+  } else { u_first = blockIdx.x * 4 + wv; u_step = nblk * 4; u_end = a.nunits; }
+  const int nstrips = Hi / a.HS;
+  // steps of a unit: q = 0 primes input rows q0 - 2, ... ; step q >= 2 runs input row iq = q0 - 1 + (q - 2), i.e. iq = q0 - 1 .. q0 + HS
+  constexpr int NPRIME = 2;
+  const int nq = a.HS + 2 + NPRIME;
+  Vec16 va = Vec16{{0, 0, 0, 0}}, vx = Vec16{{0, 0, 0, 0}};
+  auto issue = [&](int u, int q) {
+    const int n = u / nstrips, q0 = (u - n * nstrips) * a.HS;
+    const int row = q0 - 1 + q - NPRIME + 1;                                // the input row arriving at step q: one ahead of the row computed
+    va = Vec16{{0, 0, 0, 0}}; vx = Vec16{{0, 0, 0, 0}};
+    if (row >= 0 && row < Hi) {
+      const long off = (((long)n * Hi + row) * WIN) * CB + lane * 16;
+      va = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.y1) + off);
+      vx = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.xin) + off);
+    }
+  };
+  auto commit = [&](int u, int q) {
+    const int n = u / nstrips, q0 = (u - n * nstrips) * a.HS;
+    const int row = q0 - 1 + q - NPRIME + 1;
+    Vec16 ca = va, cx = vx;
+    if (row >= 0 && row < Hi) {
+      float f[8];
+      Elem<bf16_t>::unpack(ca, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * p1s[j] + p1b[j], 0.f);
+      ca = Elem<bf16_t>::pack(f);
+      if (PRO_X) {
+        Elem<bf16_t>::unpack(cx, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * pxs[j] + pxb[j], 0.f);
+        cx = Elem<bf16_t>::pack(f);
+      }
+    }
+    const int slot = (row + 4 * NSLOT) % NSLOT;
+    *reinterpret_cast<Vec16*>(ringA + slot * IROWB + CB + lane * 16) = ca;
+    *reinterpret_cast<Vec16*>(ringX + slot * IROWB + CB + lane * 16) = cx;
+    (void)n;
+  };
+  int u = u_first, q = 0;
+  if (u < u_end) issue(u, 0);
+  while (u < u_end) {
+    commit(u, q);
+    int un = u, qn = q + 1;
+    if (qn == nq) { un = u + u_step; qn = 0; }
+    if (un < u_end) issue(un, qn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q >= NPRIME) {
+      const int n = u / nstrips, q0 = (u - n * nstrips) * a.HS;
+      const int iq = q0 - 1 + q - NPRIME;                                   // input row of this step: q0 - 1 .. q0 + HS
+      const bool inside = iq >= 0 && iq < Hi;                               // (wave-uniform) rows outside the image: the tail conv's zero padding
+      // ---- the two joined rows 2 iq, 2 iq + 1
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        char* jrow = ringJ + ((2 * iq + ph + 8 * NSLOT) % NSLOT) * JROWB;
+        if (!inside) {
+          for (int i = lane; i < (W * CB) / 16; i += 64) *reinterpret_cast<Vec16*>(jrow + CB + i * 16) = Vec16{{0, 0, 0, 0}};
+          continue;
+        }
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) {
+          f32x4 acc2[2], accS[2];
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) { acc2[pt] = (f32x4){0, 0, 0, 0}; accS[pt] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+          for (int th = 0; th < 2; ++th) {
+            const int dh = ph == 0 ? (th == 0 ? 0 : -1) : (th == 0 ? 1 : 0);
+            const int sl = (iq + dh + 4 * NSLOT) % NSLOT;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+              const int off = sl * IROWB + (16 * pt + r + dwl[pw] + 1) * CB + (gq & 1) * 16;
+              acc2[pt] = mma_bf16(w2A[2 * ph + pw][th], *reinterpret_cast<const Vec16*>(ringA + off), acc2[pt]);
+              accS[pt] = mma_bf16(wuA[2 * ph + pw][th], *reinterpret_cast<const Vec16*>(ringX + off), accS[pt]);
+            }
+          }
+          // lane (r = input column p, gq) holds output channels 4gq .. 4gq+3 of output pixel 2p + pw: round like the stored tensors, join
+#pragma unroll
+          for (int pt = 0; pt < 2; ++pt) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaxf(acc2[pt][j] * js2[j] + jb[j] + accS[pt][j] * jss[j], 0.f);
+            *reinterpret_cast<uint2*>(jrow + (1 + 2 * (16 * pt + r) + pw) * CB + gq * 8) = make_uint2(pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]));
+          }
+        }
+      }
+      // ---- the tail conv's output rows that have all three joined rows now: 2 iq - 1 and 2 iq (inside the strip and the image)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int oh = 2 * iq - 1 + k;
+        if (oh < 2 * q0 || oh >= 2 * (q0 + a.HS) || oh < 0 || oh >= H) continue;
+        f32x4 acc[4];
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[pt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const char* rowp = ringJ + ((oh - 1 + kh + 8 * NSLOT) % NSLOT) * JROWB;
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+              const int kw = 2 * half + (gq >> 1);
+              const Vec16 b = *reinterpret_cast<const Vec16*>(rowp + (16 * pt + r + (kw < 3 ? kw : 0)) * CB + (gq & 1) * 16);
+              acc[pt] = mma_bf16(wT[kh][half], b, acc[pt]);
+            }
+        }
+        if (gq == 0) {
+          float* orow = a.r_raw + ((long)n * H + oh) * W + r;
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) {
+            const float v = acc[pt][0] + bias;
+            orow[16 * pt] = v;
+            st1 += v; st2 += v * v;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u = un; q = qn;
+  }
+  st1 = row16_sum(st1); st2 = row16_sum(st2);
+  float* sb = reinterpret_cast<float*>(smem);
+  if (lane == 0) { sb[wv * 2] = st1; sb[wv * 2 + 1] = st2; }
+  __syncthreads();
+  if (a.stats && t < 2) a.stats[(long)blockIdx.x * 2 + t] = (sb[t] + sb[2 + t]) + (sb[4 + t] + sb[6 + t]);
+}
+
+bool up5_tail_fwd_ok(int dt, int OC, int C, int Cin, int Hin, int Hout) {
+  static const bool env = [] { const char* e = getenv("MMVAE_TAIL_RECOMPUTE"); return !(e && e[0] == '0'); }();
+  return env && dt == DT_BF16 && OC == 1 && C == 16 && Cin == 16 && Hin == 32 && Hout == 64;
+}
+// returns the number of partial rows [rows][2] (> 0) or an error
+int launch_up5_tail_fwd(const void* y1, const float* p1s, const float* p1b, const void* w2_up, const void* xin, const float* pxs, const float* pxb,
+                        const void* wu_up, const float* s2, const float* b2, const float* ss, const float* bs, const float* w, const float* bias,
+                        float* r_raw, float* stats, int N, hipStream_t s) {
+  Up5TailFwdArgs a; memset(&a, 0, sizeof(a));
+  a.y1 = y1; a.p1s = p1s; a.p1b = p1b; a.w2 = w2_up; a.xin = xin; a.pxs = pxs; a.pxb = pxb; a.wu = wu_up;
+  a.s2 = s2; a.b2 = b2; a.ss = ss; a.bs = bs; a.w = w; a.bias = bias; a.r_raw = r_raw; a.stats = stats;
+  a.N = N; a.HS = 16; a.nunits = N * (32 / a.HS);
+  int gx = 512;                                              // two blocks per CU (LDS), one resident round; rows of `stats` <= N
+  while (gx > 1 && (long)gx * 4 > a.nunits) gx -= gx > 8 ? 8 : 1;
+  const size_t lds = 64 + 4 * (size_t)(2 * 4 * 34 * 32 + 4 * 66 * 32);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&up5_tail_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&up5_tail_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { set_error("up5_tail_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MMVAE_ERR_HIP; }
+    attr_set = true;
+  }
+  if (pxs) hipLaunchKernelGGL(up5_tail_fwd_kernel<true>, dim3(gx), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(up5_tail_fwd_kernel<false>, dim3(gx), dim3(256), lds, s, a);
+  note_launch_bytes((double)N * (2.0 * 32 * 32 * 16 * 2 + 64 * 64 * 4.0));
+  const int rc = check_launch("up5_tail_fwd");
+  return rc ? rc : gx;
+}
+
 bool convT4_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win) {
   static const bool env = [] { const char* e = getenv("MMVAE_CONVT4_STREAM"); return !(e && e[0] == '0'); }();
   return env && dt == DT_BF16 && Cin == 16 && Cout == 16 && k == 4 && s == 2 && p == 1 && Hin == Win && (Win == 32 || Win == 16);

@@ -224,6 +224,11 @@ int launch_convT4_stream(int dt, const void* x, const void* w_up, void* y, const
 bool tail_fwd_stream_ok(int dt, int OC, int H, int W);
 int launch_tail_fwd_stream(int dt, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs, const float* w,
                            const float* bias, float* r_raw, float* stats, int N, int H, int W, hipStream_t s, int f8in = 0);
+// the same with the two branch outputs recomputed from the ConvTranspose2d inputs instead of read (conv_fstream.hip; bf16, 32x32 -> 64x64, 16 channels)
+bool up5_tail_fwd_ok(int dt, int OC, int C, int Cin, int Hin, int Hout);
+int launch_up5_tail_fwd(const void* y1, const float* p1s, const float* p1b, const void* w2_up, const void* xin, const float* pxs, const float* pxb,
+                        const void* wu_up, const float* s2, const float* b2, const float* ss, const float* bs, const float* w, const float* bias,
+                        float* r_raw, float* stats, int N, hipStream_t s);
 // stem forward as a per-wave stream (bf16; stem_bwd.hip): returns stats rows (> 0) or an error
 bool stem_fwd_stream_ok(int dt, int S);
 int launch_stem_fwd_stream(int dt, const void* x, const float* w, void* y, float* stats, int N, int S, hipStream_t s);

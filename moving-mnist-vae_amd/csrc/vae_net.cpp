@@ -879,7 +879,13 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
   float* r_raw = reinterpret_cast<float*>(base + P.r_raw);
   if (tail_fwd_fused()) {
     const Block& B = dec.back();
-    if (tail_fwd_stream_ok(dt(), cfg.out_ch, Sd, Sd))
+    if (!store8 && !B.identity && !B.c2.fp8 && !B.cs.fp8 && tail_fwd_stream_ok(dt(), cfg.out_ch, Sd, Sd) &&
+        up5_tail_fwd_ok(dt(), cfg.out_ch, B.C, B.Cin, B.Hin, B.Hout) && convT4_stream_ok(dt(), B.c2.D0, B.c2.D1, B.c2.k, B.c2.s, B.c2.p, B.Hin, B.Win))
+      // the join + tail conv with both branch outputs recomputed from the ConvTranspose2d inputs (0.34 GB) instead of read back (1.34 GB)
+      np = launch_up5_tail_fwd(base + B.y1, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + plan_.packed + B.c2.packU * (long)esz(), xin, xs, xb,
+                               base + plan_.packed + B.cs.packU * (long)esz(), bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
+                               bnf(B.bs, base, 3), params + tail.off, params + tail_bias, r_raw, stats, N, s);
+    else if (tail_fwd_stream_ok(dt(), cfg.out_ch, Sd, Sd))
       np = launch_tail_fwd_stream(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
                                   params + tail.off, params + tail_bias, r_raw, stats, N, Sd, Sd, s, store8 ? 1 : 0);
     else if (store8) { set_error("fp8 storage of the last up-block needs tail_fwd_stream"); return MMVAE_ERR_UNSUPPORTED; }

@@ -261,3 +261,49 @@ def test_upblock_backward_in_one_pass(N, pro_x):
     gm = da1_r.float().cpu().permute(0, 3, 1, 2) * m1
     ref_sums = torch.stack([gm.sum((0, 2, 3)), (gm * y1).sum((0, 2, 3))])
     assert ((sums.cpu() - ref_sums).abs().max() / ref_sums.abs().max()).item() < 1e-2
+
+
+@pytest.mark.parametrize("N", [1, 3, 19])
+@pytest.mark.parametrize("pro_x", [False, True])
+def test_upblock_tail_forward_recomputed(N, pro_x):
+    """mmvae_upblock_tail_fwd (up5_tail_fwd_kernel: the join + tail conv with both ConvTranspose2d branch outputs recomputed from their
+    inputs) against torch fp32 on the same bf16-rounded operands: r_raw = conv2d(relu(bn2(convT(relu(bn1(y1)))) + bns(convT(x))), w) + bias
+    (model.py:70-85,193), and the output statistics.  The kernel keeps the recomputed branch outputs in f32 and rounds the two activations
+    it feeds to the MFMA (the ConvTranspose2d inputs, the joined rows) to bf16: tolerance 1e-2 of the output's range, like the stored-tensor
+    form's test above."""
+    L = _lib()
+    lib = L.lib()
+    g = torch.Generator().manual_seed(900 + N)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    vec = lambda lo, hi: torch.rand(16, generator=g) * (hi - lo) + lo
+    y1, xin = bf(torch.randn(N, 16, 32, 32, generator=g)), bf(torch.randn(N, 16, 32, 32, generator=g))
+    s1, b1 = vec(0.5, 1.5), vec(-0.3, 0.3)
+    sx, bx = (vec(0.5, 1.5), vec(-0.3, 0.3)) if pro_x else (None, None)
+    w2, wu = torch.randn(16, 16, 4, 4, generator=g) / 8.0, torch.randn(16, 16, 4, 4, generator=g) / 8.0
+    s2, ss, b2, bs = vec(0.5, 1.5), vec(0.5, 1.5), vec(-0.3, 0.3), vec(-0.3, 0.3)
+    tw, tb = torch.randn(1, 16, 3, 3, generator=g) / 12.0, torch.randn(1, generator=g)
+    v4 = lambda t: t.view(1, -1, 1, 1)
+    a1 = bf(torch.relu(y1 * v4(s1) + v4(b1)))
+    ax = bf(torch.relu(xin * v4(sx) + v4(bx))) if pro_x else xin
+    y2 = F.conv_transpose2d(a1, bf(w2), None, stride=2, padding=1)
+    ys = F.conv_transpose2d(ax, bf(wu), None, stride=2, padding=1)
+    x = bf(torch.relu(y2 * v4(s2) + v4(b2) + ys * v4(ss) + v4(bs)))
+    ref = F.conv2d(x, bf(tw), tb, padding=1)
+    cu = lambda t: None if t is None else t.cuda()
+    P = L.ptr
+    d = {k: cu(v) for k, v in dict(s1=s1, b1=b1, sx=sx, bx=bx, w2=w2, wu=wu, s2=s2, b2=b2, ss=ss, bs=bs, tw=tw, tb=tb).items()}
+    y1d, xind = _nhwc(y1, "bf16"), _nhwc(xin, "bf16")
+    out = torch.full((N, 1, 64, 64), float("nan"), device="cuda")
+    stats = torch.full((max(N, 8), 2), float("nan"), device="cuda")
+    sc = torch.empty(65536, dtype=torch.uint8, device="cuda")
+    rows = lib.mmvae_upblock_tail_fwd(P(y1d), P(d["s1"]), P(d["b1"]), P(d["w2"]), P(xind), P(d["sx"]), P(d["bx"]), P(d["wu"]), P(d["s2"]), P(d["b2"]),
+                                      P(d["ss"]), P(d["bs"]), P(d["tw"]), P(d["tb"]), P(out), P(stats), N, P(sc), torch.cuda.current_stream().cuda_stream)
+    L.check(rows, "upblock_tail_fwd")
+    torch.cuda.synchronize()
+    assert 0 < rows <= stats.shape[0]
+    got = out.cpu()
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err < 1e-2, (N, pro_x, err)
+    sums = stats[:rows].sum(0).cpu()
+    assert abs(sums[0].item() - got.double().sum().item()) <= 1e-3 * got.double().abs().sum().item()
+    assert abs(sums[1].item() - (got.double() ** 2).sum().item()) <= 1e-4 * (got.double() ** 2).sum().item()
