@@ -170,6 +170,16 @@ int op_run_wgrad_pair(int dt, const ConvGeom& g, const ConvGeom& gs, int N, cons
   return try_wgrad_stream_pair(dt, a, P2, dW2, scale2, s);
 }
 
+// whether op_run_wgrad runs this layer on the per-wave stream kernel (whose partial images are <= 19 MB and whose reduce can be deferred)
+bool op_wgrad_is_stream(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl, bool proP, bool proG) {
+  if (g.k * g.k > 25) return false;
+  WgradArgs a;
+  float dummy = 0.f;
+  wgrad_args(a, g, N, nullptr, Hs, Ws, proP ? &dummy : nullptr, proP ? &dummy : nullptr, 1, nullptr, Hl, Wl, proG ? &dummy : nullptr, proG ? &dummy : nullptr, 1,
+             nullptr, &dummy, 1.f);
+  return wgrad_stream_shape(dt, a);
+}
+
 bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl) {
   if (g.k * g.k > 25) return false;
   WgradArgs a;

@@ -501,6 +501,11 @@ static int wstream_reduce(const WgradArgs& a, int gx, hipStream_t s, bool x2 = f
   return launch_wgrad_reduce(v, s);
 }
 
+// whether try_wgrad_stream takes this weight gradient (callers that hand it a smaller scratch or defer its reduce ask first)
+bool wgrad_stream_shape(int dt, const WgradArgs& a) {
+  return wstream_kind(dt, a) != 0 && !(a.proP_scale && a.proG_scale);
+}
+
 // Returns 1 when the launch was taken (kernel + reduce enqueued), 0 when the shape is not this kernel's, <0 on error.  MMVAE_WSTREAM=0: off
 int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s) {
   const int kind = wstream_kind(dt, a);

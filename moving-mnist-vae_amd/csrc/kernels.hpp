@@ -67,6 +67,7 @@ struct WgradArgs {
                                    // launch took another kernel and reduced at once) -- the caller launches it later, off the busy phase
 };
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
+bool wgrad_stream_shape(int dt, const WgradArgs& a);
 int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s);   // conv_wstream.hip: 1 = taken, 0 = not this kernel's shape, <0 error
 int try_wgrad_stream_pair(int dt, const WgradArgs& a, const void* P2, float* dW2, float scale2, hipStream_t s);
 // weight gradient + data gradient (w.r.t. P) of a 16 -> 16 channel k4 s2 layer in one pass over G (conv_wstream.hip)

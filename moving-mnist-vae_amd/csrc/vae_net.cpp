@@ -714,7 +714,7 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // AFTER the block's other weight gradient has been enqueued -- under the stem backward's load a 19 MB reduce takes 120 us instead of
     // 10, and it sat in front of the last big kernel of the side stream
     WgradReduceArgs late; late.nparts = 0;
-    if (i == 0 && wsm != s)
+    if (i == 0 && wsm != s && !B.c2.fp8 && op_wgrad_is_stream(dt(), geom(B.c2), N, B.Hout, B.Wout, B.Hout, B.Wout, false, true))
       MM_TRY(op_run_wgrad(dt(), geom(B.c2), N, base + dy2o, B.Hout, B.Wout, nullptr, nullptr, 1, base + B.y1, B.Hout, B.Wout, bnf(B.b1, base, 2),
                           bnf(B.b1, base, 3), 1, grads + B.c2.off, wsm, reinterpret_cast<float*>(base + P.wscratch2), B.c2.wscale, &late));
     else
