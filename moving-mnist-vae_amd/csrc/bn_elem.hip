@@ -783,9 +783,10 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ch = 4 * gq + j;
-    msc[j] = ms[ch]; msh[j] = mb[ch]; msc1[j] = ms1[ch]; msh1[j] = mb1[ch];
+    msc[j] = ms[ch]; msh[j] = mb[ch] + mb1[ch]; msc1[j] = ms1[ch]; msh1[j] = 0.f;      // (the join's two shifts added up front)
     acc[0][j] = 0.f; acc[1][j] = 0.f; acc[2][j] = 0.f;
   }
+  (void)msh1;
   f32x4 macc = {0.f, 0.f, 0.f, 0.f};
   char* sXw = reinterpret_cast<char*>(sX + wv * 512);
   const int p0 = 32 * wv, pr = p0 >> tg.wshift, c0 = p0 & (W - 1);     // the wave's 32 pixels: one row (W >= 32)
@@ -835,10 +836,12 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
     for (int pt = 0; pt < 2; ++pt) {
       const int base = (pr + 2) * pitch + c0 + 16 * pt + r + 2;
       // B[k = 8gq + t][pixel r]: taps 0..7 (even gq) / tap 8 in slot 0 (odd gq); hi parts (gq < 2) / lo parts (gq >= 2)
+      // (odd gq: only k-slot 0 = tap 8 meets a non-zero weight in wA; its other seven values are finite staged data and multiply zeros --
+      // no per-element selects, constant offsets from one base)
       float dv[8];
       dv[0] = img[base - (odd ? 2 * pitch + 2 : 0)];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) dv[k] = img[odd ? zoff : base - (k / 3) * pitch - (k % 3)];
+      for (int k = 1; k < 8; ++k) dv[k] = img[base - (k / 3) * pitch - (k % 3)];
       Vec16 bf;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(256, 4) void tail_reduce_mfma_kernel(TailG tg, cons
       float x[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        x[j] = fmaxf((f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]), 0.f);
+        x[j] = fmaxf(f1[j] * msc1[j] + (f0[j] * msc[j] + msh[j]), 0.f);
         const float gg = x[j] > 0.f ? g[j] : 0.f;
         acc[0][j] += gg; acc[1][j] += gg * f0[j]; acc[2][j] += gg * f1[j];
       }

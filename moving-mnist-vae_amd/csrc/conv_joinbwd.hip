@@ -97,13 +97,16 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
     const int t0 = 8 * (gq & 1) + 2 * k;
     wA.w[k] = pack2_bf16(t0 < 9 ? a.w_tail[r * 9 + t0] : 0.f, t0 + 1 < 9 ? a.w_tail[r * 9 + t0 + 1] : 0.f);
   }
-  float msc[4], msh[4], msc1[4], msh1[4], ca0[4], cb0[4], cc0[4], ca1[4], cb1[4], cc1[4], bsc[4], bsh[4];
+  // (channel pairs as 2-vectors: the producer's affine arithmetic runs on v_pk_fma_f32; the join's two shifts are added up front)
+  f32x2_t msc[2], msh[2], msc1[2], ca0[2], cb0[2], cc0[2], ca1[2], cb1[2], cc1[2];
+  float bsc[4], bsh[4];
   float bs0[4] = {0, 0, 0, 0}, bs1[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ch = 4 * gq + j;
-    msc[j] = a.ms2[ch]; msh[j] = a.mb2[ch]; msc1[j] = a.mss[ch]; msh1[j] = a.mbs[ch];
-    ca0[j] = a.A2[ch]; cb0[j] = a.B2[ch]; cc0[j] = a.C2[ch]; ca1[j] = a.As[ch]; cb1[j] = a.Bs[ch]; cc1[j] = a.Cs[ch];
+    msc[j >> 1][j & 1] = a.ms2[ch]; msh[j >> 1][j & 1] = a.mb2[ch] + a.mbs[ch]; msc1[j >> 1][j & 1] = a.mss[ch];
+    ca0[j >> 1][j & 1] = a.A2[ch]; cb0[j >> 1][j & 1] = a.B2[ch]; cc0[j >> 1][j & 1] = a.C2[ch];
+    ca1[j >> 1][j & 1] = a.As[ch]; cb1[j >> 1][j & 1] = a.Bs[ch]; cc1[j >> 1][j & 1] = a.Cs[ch];
     bsc[j] = a.p1s[ch]; bsh[j] = a.p1b[ch];
   }
   // ---- prologue coefficients of this wave's P row (8 consecutive channels per 16-byte vector: lane & 1 selects the half);
@@ -250,11 +253,13 @@ __global__ __launch_bounds__(128 * PAIRS, 2) void join_bwd_stream_kernel(JoinBwd
       else { unpack4_bf16(v2, f0); unpack4_bf16(vs, f1); }
       float r0[4], r1[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float x = (f0[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]);
-        const float gg = x > 0.f ? g[j] : 0.f;
-        r0[j] = ca0[j] * gg + cb0[j] * f0[j] + cc0[j];
-        r1[j] = ca1[j] * gg + cb1[j] * f1[j] + cc1[j];
+      for (int h = 0; h < 2; ++h) {
+        const f32x2_t v0 = {f0[2 * h], f0[2 * h + 1]}, v1 = {f1[2 * h], f1[2 * h + 1]};
+        const f32x2_t x = __builtin_elementwise_fma(v1, msc1[h], __builtin_elementwise_fma(v0, msc[h], msh[h]));
+        const f32x2_t gg = {x[0] > 0.f ? g[2 * h] : 0.f, x[1] > 0.f ? g[2 * h + 1] : 0.f};
+        const f32x2_t q0 = __builtin_elementwise_fma(ca0[h], gg, __builtin_elementwise_fma(cb0[h], v0, cc0[h]));
+        const f32x2_t q1 = __builtin_elementwise_fma(ca1[h], gg, __builtin_elementwise_fma(cb1[h], v1, cc1[h]));
+        r0[2 * h] = q0[0]; r0[2 * h + 1] = q0[1]; r1[2 * h] = q1[0]; r1[2 * h + 1] = q1[1];
       }
       *reinterpret_cast<uint2*>(ringA + slot * ROWB + (PAD + 16 * pt + r) * 32 + gq * 8) = make_uint2(pack2_bf16(r0[0], r0[1]), pack2_bf16(r0[2], r0[3]));
       *reinterpret_cast<uint2*>(ringB + slot * ROWB + (PAD + 16 * pt + r) * 32 + gq * 8) = make_uint2(pack2_bf16(r1[0], r1[1]), pack2_bf16(r1[2], r1[3]));
