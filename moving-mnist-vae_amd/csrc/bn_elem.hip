@@ -127,13 +127,6 @@ __global__ __launch_bounds__(256) void plane_reduce_nchw_kernel(const float* __r
 
 static int nchw_parts(int N, int C) { int p = N * C; return p > 1024 ? 1024 : (p < 1 ? 1 : p); }
 
-int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials, hipStream_t s) {
-  const int blocks = nchw_parts(N, C);
-  const size_t sm = (size_t)4 * 2 * C * sizeof(float);
-  hipLaunchKernelGGL((plane_reduce_nchw_kernel<2>), dim3(blocks), dim3(256), sm, s, y, (const float*)nullptr, N, C, HW, partials);
-  int rc = check_launch("chan_stats_nchw");
-  return rc ? rc : blocks;
-}
 
 int launch_bn_bwd_reduce_nchw(const float* dout, const float* y, int N, int C, int HW, float* partials, hipStream_t s) {
   const int blocks = nchw_parts(N, C);
@@ -201,22 +194,6 @@ __global__ void bn_finalize_kernel(BnFinalizeArgs a) {
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(a.C), dim3(256), 0, s, a);
   return check_launch("bn_finalize");
-}
-
-__global__ void bn_eval_affine_kernel(const float* g, const float* b, const float* rm, const float* rv, float eps, int C,
-                                      float* scale, float* shift, float in_scale) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    const float istd = 1.0f / sqrtf(rv[c] + eps);
-    const float sc = g[c] * istd;
-    scale[c] = sc / in_scale;              // the input is y' = in_scale * y
-    shift[c] = b[c] - rm[c] * sc;
-  }
-}
-int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
-                          float* scale, float* shift, hipStream_t s, float in_scale) {
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, eps, C, scale, shift, in_scale);
-  return check_launch("bn_eval_affine");
 }
 
 // Inference (model.eval(), reference model.py:353-362): every BatchNorm of an entry point folded into its per-channel (scale, shift) pair from the
@@ -1189,110 +1166,8 @@ int launch_tail_join_fwd(int dt, const void* y0, const float* ms, const float* m
   return rc ? rc : N;
 }
 
-// ---------------------------------------------------------------- tail conv weight gradient, one output plane
-// dW[0][ci][kh][kw] = sum_{n,h,w} out[n,h,w,ci] * d_raw[n, h+1-kh, w+1-kw]: the same tile walk and LDS d_raw tile as the join
-// backward above, with 9 x VE accumulators per thread instead of an MFMA tile (a 16 x 9 result over 21 M pixels is a
-// reduction, not a GEMM: the MFMA wgrad spends its time transposing operands and reaches 1.4 TB/s on it).
-// Deterministic: per-block partials [block][144] in (ci, tap) order, summed by tail_wgrad_finalize_kernel.
-// JOIN: x is not stored (fused forward above) and is recomputed as relu(bn(x) + bn(x1)) from the two branch outputs.
-template <typename T, bool JOIN>
-__global__ __launch_bounds__(256) void tail_wgrad_tile_kernel(TailG tg, const T* __restrict__ x, const T* __restrict__ x1,
-                                                              const float* __restrict__ ms, const float* __restrict__ mb,
-                                                              const float* __restrict__ ms1, const float* __restrict__ mb1,
-                                                              float* __restrict__ partials) {
-  constexpr int VE = Elem<T>::kVec;
-  constexpr int CV = 16 / VE, PT = 256 / CV;
-  extern __shared__ float smem[];
-  const int W = tg.W, H = tg.H, hw = H * W;
-  const int R = PT >> tg.wshift, pitch = W + 2, rows = R + 2;
-  const int tile_floats = rows * pitch;
-  float* sD = smem;                                  // [2][rows][pitch]
-  float* sR = smem + 2 * tile_floats;                // [4 waves][CV][9 * VE]
-  const int tid = threadIdx.x, p = tid / CV;
-  const int pr = p >> tg.wshift, pc = p & (W - 1);
-  for (int i = tid; i < 2 * tile_floats; i += 256) sD[i] = 0.f;
-  float msc[VE], msh[VE], msc1[VE], msh1[VE];
-  if (JOIN) {
-#pragma unroll
-    for (int j = 0; j < VE; ++j) { const int ch = (tid % CV) * VE + j; msc[j] = ms[ch]; msh[j] = mb[ch]; msc1[j] = ms1[ch]; msh1[j] = mb1[ch]; }
-  }
-  float acc[9][VE];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int j = 0; j < VE; ++j) acc[t][j] = 0.f;
-  __syncthreads();
-  const int stage = rows * W;
-  const int G = gridDim.x;
-  Vec16 q[2], r[2];                                  // x (and x1) vectors of the next two tiles
-  float dpre[2] = {0.f, 0.f};
-  auto fetch_d = [&](int t) {
-    const int pix0 = t * PT, n = pix0 / hw, h0 = (pix0 - n * hw) >> tg.wshift;      // uniform
-    const float* dp = tg.d_raw + (long)n * hw;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int e = tid + k * 256, r = e >> tg.wshift, c = e & (W - 1), h = h0 - 1 + r;
-      dpre[k] = (e < stage && h >= 0 && h < H) ? dp[h * W + c] : 0.f;
-    }
-  };
-  const int t0 = blockIdx.x;
-  auto fetch_x = [&](int t, int slot) {
-    q[slot] = reinterpret_cast<const Vec16*>(x)[(long)t * 256 + tid];
-    if (JOIN) r[slot] = reinterpret_cast<const Vec16*>(x1)[(long)t * 256 + tid];
-  };
-  if (t0 < tg.ntiles) { fetch_x(t0, 0); fetch_d(t0); }
-  if (t0 + G < tg.ntiles) fetch_x(t0 + G, 1);
-  int buf = 0;
-  for (int t = t0; t < tg.ntiles; t += G, buf ^= 1) {
-    float* sT = sD + buf * tile_floats;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int e = tid + k * 256, r = e >> tg.wshift, c = e & (W - 1);
-      if (e < stage) sT[r * pitch + c + 1] = dpre[k];
-    }
-    float f[VE];
-    Elem<T>::unpack(q[0], f);
-    if (JOIN) {
-      float f1[VE];
-      Elem<T>::unpack(r[0], f1);
-#pragma unroll
-      for (int j = 0; j < VE; ++j) f[j] = fmaxf((f[j] * msc[j] + msh[j]) + (f1[j] * msc1[j] + msh1[j]), 0.f);
-      r[0] = r[1];
-    }
-    q[0] = q[1];
-    if (t + G < tg.ntiles) fetch_d(t + G);
-    if (t + 2 * G < tg.ntiles) fetch_x(t + 2 * G, 1);
-    __syncthreads();
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const float d = sT[(pr + 2 - kh) * pitch + pc + 2 - kw];
-#pragma unroll
-        for (int j = 0; j < VE; ++j) acc[kh * 3 + kw][j] += d * f[j];
-      }
-  }
-  // lanes with equal (lane % CV) share channels: butterfly over the other lane bits, then the four waves through LDS
-  const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int j = 0; j < VE; ++j) {
-      float v = acc[t][j];
-#pragma unroll
-      for (int m = CV; m < 64; m <<= 1) v += __shfl_xor(v, m);
-      if (lane < CV) sR[(wv * CV + lane) * 9 * VE + t * VE + j] = v;
-    }
-  __syncthreads();
-  if (tid < 144) {
-    const int ci = tid / 9, t = tid - ci * 9, cg = ci / VE, j = ci - cg * VE;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) v += sR[(w * CV + cg) * 9 * VE + t * VE + j];
-    partials[(long)blockIdx.x * 144 + tid] = v;
-  }
-}
 
+// ---------------------------------------------------------------- NCHW f32 elementwise (output BN)
 __global__ __launch_bounds__(64) void tail_wgrad_finalize_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ dW) {
   double s = 0.0;
   for (int p = threadIdx.x; p < nparts; p += 64) s += (double)partials[(long)p * 144 + blockIdx.x];
@@ -1305,29 +1180,6 @@ int launch_tail_wgrad_finalize(const float* wpartials, int nparts, float* dW, hi
   return check_launch("tail_wgrad_finalize");
 }
 
-// x = the tail conv's input (NHWC, 16 channels), d_raw = its output gradient (one f32 plane); dW[16][3][3] is accumulated into.
-// scratch: at least 1024 * 144 floats.  The geometry must pass tail_join_fusable(dt, 1, N, H, W).
-// x1 != NULL: x, x1 are the two branch outputs and (ms, mb), (ms1, mb1) their BatchNorm scale/shift (the joined input is recomputed).
-int launch_tail_wgrad_tile(int dt, const void* x, const void* x1, const float* ms, const float* mb, const float* ms1, const float* mb1,
-                           const float* d_raw, float* dW, float* scratch, int N, int H, int W, hipStream_t s) {
-  if (!tail_join_fusable(dt, 1, N, H, W)) { set_error("tail_wgrad_tile: H=%d W=%d not supported", H, W); return MMVAE_ERR_UNSUPPORTED; }
-  const int VE = dt == DT_F32 ? 4 : 8, cv = 16 / VE, pt = 256 / cv;
-  int wshift = 0;
-  while ((1 << wshift) < W) ++wshift;
-  const int ntiles = (int)((long)N * H * W / pt);
-  const int blocks = ntiles < 1024 ? ntiles : 1024;
-  const TailG tg{d_raw, nullptr, 1, H, W, wshift, ntiles};
-  const size_t sm = ((size_t)2 * (pt / W + 2) * (W + 2) + 4 * cv * 9 * VE) * sizeof(float);
-#define MMVAE_LAUNCH(T, JOIN) hipLaunchKernelGGL((tail_wgrad_tile_kernel<T, JOIN>), dim3(blocks), dim3(256), sm, s, tg, (const T*)x, (const T*)x1, \
-    ms, mb, ms1, mb1, scratch)
-  if (dt == DT_F32) { if (x1) MMVAE_LAUNCH(float, true); else MMVAE_LAUNCH(float, false); }
-  else { if (x1) MMVAE_LAUNCH(bf16_t, true); else MMVAE_LAUNCH(bf16_t, false); }
-#undef MMVAE_LAUNCH
-  hipLaunchKernelGGL(tail_wgrad_finalize_kernel, dim3(144), dim3(64), 0, s, scratch, blocks, dW);
-  return check_launch("tail_wgrad_tile");
-}
-
-// ---------------------------------------------------------------- NCHW f32 elementwise (output BN)
 __global__ void affine_nchw_kernel(const float* __restrict__ raw, const float* __restrict__ scale, const float* __restrict__ shift,
                                    float* __restrict__ out, long total, int C, int HW) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

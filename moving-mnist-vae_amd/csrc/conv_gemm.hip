@@ -284,59 +284,6 @@ bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, 
 
 constexpr size_t kV2MaxLds = 60 * 1024;
 
-// Returns >0 (stats rows) when the v2 kernel ran, 0 when the launch is not eligible, <0 on error.
-static int try_gather2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
-  const bool boundary = a.x_planar || a.y_planes;      // these layouts exist only in the patch-tile kernel
-  if ((conv_force_v1() && !boundary) || a.Cout > 64 || a.Cin > 512) return 0;
-  if (boundary && ((a.x_planar && (a.Cin > 16 || a.x_planes > a.Cin)) || (a.y_planes && (a.Cout != 16 || a.y_planes > 16)))) return 0;
-  Gather2Args b; memset(&b, 0, sizeof(b));
-  b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
-  b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate;
-  b.Cin = a.Cin; b.Cout = a.Cout; b.Ho = a.Ho; b.Wo = a.Wo; b.SO = a.SO; b.nphase = a.nphase;
-  b.x_planar = a.x_planar; b.x_planes = a.x_planes; b.y_planes = a.y_planes;
-  int max_tiles = 0;
-  int span[kMaxPhases][4];
-  for (int p = 0; p < a.nphase; ++p) {
-    const Phase& ph = a.phases[p];
-    int dh0 = 0, dh1 = 0, dw0 = 0, dw1 = 0;
-    for (int t = 0; t < ph.ntaps; ++t) {
-      const Tap tp = a.taps[ph.tap0 + t];
-      if (t == 0) { dh0 = dh1 = tp.dh; dw0 = dw1 = tp.dw; }
-      dh0 = tp.dh < dh0 ? tp.dh : dh0; dh1 = tp.dh > dh1 ? tp.dh : dh1;
-      dw0 = tp.dw < dw0 ? tp.dw : dw0; dw1 = tp.dw > dw1 ? tp.dw : dw1;
-    }
-    Phase2& q = b.phases[p];
-    q.ph = ph.ph; q.pw = ph.pw; q.ntaps = ph.ntaps; q.tap0 = ph.tap0; q.w_off = ph.w_off;
-    span[p][0] = dh0; span[p][1] = dw0; span[p][2] = dh1 - dh0 + 1; span[p][3] = dw1 - dw0 + 1;
-  }
-  for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
-  const int CT = ((a.Cout + 15) / 16 == 3 ? 4 : (a.Cout + 15) / 16) * 16;
-  // largest tile (4, 2 or 1 sub-tiles of 128 pixels per barrier pair) that fits LDS and still leaves >= 1024 tiles
-  size_t lds = 0;
-  bool ok = false;
-  // multi-sub-tile tiles pay off only for the wide, shallow boundary layers (tail conv: 64-wide rows, tiny patches);
-  // elsewhere occupancy beats tile size (measured)
-  for (int sub = boundary ? 4 : 1; sub >= 1 && !ok; sub >>= 1) {
-    bool geo = true;
-    max_tiles = 0;
-    for (int p = 0; p < a.nphase && geo; ++p) {
-      const Phase& ph = a.phases[p];
-      geo = make_tile_geom(b.phases[p].g, a.N, ph.Hq, ph.Wq, a.Hi, a.Wi, a.SI, span[p][0], span[p][1], span[p][2], span[p][3], 128, sub);
-      if (geo && b.phases[p].g.ntiles > max_tiles) max_tiles = b.phases[p].g.ntiles;
-    }
-    if (!geo) continue;
-    if (sub > 1 && max_tiles * a.nphase < 1024) continue;
-    lds = gather2_lds_bytes(b, dt, CT);
-    ok = lds <= kV2MaxLds;
-  }
-  if (!ok) return 0;
-  int occ = (int)((160 * 1024) / lds); if (occ > 4) occ = 4; if (occ < 1) occ = 1;
-  int gx = (256 * occ) / a.nphase; if (gx < 1) gx = 1;
-  if (gx > max_tiles) gx = max_tiles;
-  if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
-  return launch_gather2(dt, out_dt, b, gx, s);
-}
-
 // Pipelined all-phases patch kernel: eligible when the weights of every phase together with one patch fit LDS.
 // Returns >0 (stats rows) when it ran, 0 when not eligible, <0 on error.
 static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
@@ -692,8 +639,6 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
         return launch_gather3(dt, out_dt, a, (int)gx3, s);
       }
     }
-    const int rc2 = try_gather2(dt, out_dt, a, s);
-    if (rc2 != 0) return rc2;      // >0: launched (stats rows), <0: error, 0: not eligible -> generic kernel
     if (a.x_planar || a.y_planes) { set_error("gather_gemm: planar boundary layouts need the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }
   }
   const int gx = max_tiles < kGatherMaxGridX ? max_tiles : kGatherMaxGridX;

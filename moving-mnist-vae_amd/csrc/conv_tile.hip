@@ -125,206 +125,6 @@ template <> __device__ __forceinline__ void store4v<bf16_t>(bf16_t* p, const flo
 
 // ============================================================================ gather2
 // LDS carve: [weights: Cout rows x (kvp+1) vec][patch][sKoff: kvp ints][sPro: 1024 floats][sStat: 8*CT floats]
-template <typename T, typename TO, int CT16>
-__global__ __launch_bounds__(256) void gather2_kernel(Gather2Args a) {
-  constexpr int VE = Elem<T>::kVec;
-  constexpr int ES = sizeof(T);
-  constexpr int CT = CT16 * 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const Phase2 P = a.phases[blockIdx.z];
-  const TileGeom g = P.g;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, gq = lane >> 4, r = lane & 15;
-  const int cin_vecs = a.Cin / VE;
-  const int kvecs = P.ntaps * cin_vecs;
-  const int kvp = (kvecs + 3) & ~3;
-  const int wrow = kvp + 1;                       // weight row stride in vec16 (pad 16 B against bank conflicts)
-  Vec16* sW = reinterpret_cast<Vec16*>(smem);
-  Vec16* sPatch = sW + CT * wrow;
-  const int patch_vecs = g.segs * g.PR * g.PW * cin_vecs;
-  int* sKoff = reinterpret_cast<int*>(sPatch + patch_vecs);
-  float* sPro = reinterpret_cast<float*>(sKoff + kvp);
-  float* sStat = sPro + 1024;
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ Wt = reinterpret_cast<const T*>(a.w) + P.w_off;
-  TO* __restrict__ Y = reinterpret_cast<TO*>(a.y);
-  const bool has_pro = a.pro_scale != nullptr;
-  // ---- block prologue: weights, k-offset table, prologue constants
-  for (int v = t; v < CT * kvp; v += 256) {
-    const int row = v / kvp, kv = v - row * kvp;
-    sW[row * wrow + kv] = (kv < kvecs && row < a.Cout) ? *reinterpret_cast<const Vec16*>(Wt + ((long)row * kvecs + kv) * VE) : Vec16{{0, 0, 0, 0}};
-  }
-  for (int v = t; v < kvp; v += 256) {
-    int off = 0;
-    if (v < kvecs) {
-      const int tap = v / cin_vecs, cv = v - tap * cin_vecs;
-      const Tap tp = a.taps[P.tap0 + tap];
-      off = (((tp.dh - g.oh) * g.PW + (tp.dw - g.ow)) * a.Cin + cv * VE) * ES;
-    }
-    sKoff[v] = off;
-  }
-  if (has_pro) for (int i = t; i < a.Cin; i += 256) { sPro[i] = a.pro_scale[i]; sPro[512 + i] = a.pro_shift[i]; }
-  float st1[CT16][4], st2[CT16][4];
-#pragma unroll
-  for (int c = 0; c < CT16; ++c)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { st1[c][j] = 0.f; st2[c][j] = 0.f; }
-  const int npix_tile = g.sub > 1 ? 128 : g.segs * g.qr * g.Wq;   // pixel slots of one sub-tile
-  const int nks = kvp >> 2;
-  const char* patch_bytes = reinterpret_cast<const char*>(sPatch);
-  // tile-independent decode of this lane's two pixels
-  int pbase[2], pseg[2], pj[2], pwq[2];
-#pragma unroll
-  for (int pt = 0; pt < 2; ++pt) {
-    const int p = 32 * wv + 16 * pt + r;
-    const int pc = p < npix_tile ? p : 0;
-    pbase[pt] = patch_index(g, pc) * a.Cin * ES;
-    const int per_seg = g.qr * g.Wq;
-    pseg[pt] = pc / per_seg;
-    const int rem = pc - pseg[pt] * per_seg;
-    pj[pt] = rem / g.Wq;
-    pwq[pt] = rem - pj[pt] * g.Wq;
-    if (p >= npix_tile) pseg[pt] = -1;
-  }
-
-  for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-    __syncthreads();                 // previous tile's fragment reads are done (also orders the block prologue)
-    if (a.x_planar == 0) stage_patch<T, 4>(g, tile, X, a.Cin, 0, a.Cin, has_pro ? sPro : nullptr, a.pro_relu, sPatch);
-    else if (a.x_planar == 1) stage_patch_planar<T, float>(g, tile, reinterpret_cast<const float*>(a.x), a.x_planes, a.Cin, sPatch);
-    else stage_patch_planar<T, T>(g, tile, X, a.x_planes, a.Cin, sPatch);
-    __syncthreads();
-   for (int sb = 0; sb < g.sub; ++sb) {
-    const int sub_off = sb * g.sub_pix * a.Cin * ES;
-    f32x4 acc[CT16][2];
-#pragma unroll
-    for (int c = 0; c < CT16; ++c) { acc[c][0] = (f32x4){0, 0, 0, 0}; acc[c][1] = (f32x4){0, 0, 0, 0}; }
-    for (int ks = 0; ks < nks; ++ks) {
-      const int kv = 4 * ks + gq;
-      const int koff = sKoff[kv] + sub_off;
-      const Vec16 b0 = *reinterpret_cast<const Vec16*>(patch_bytes + pbase[0] + koff);
-      const Vec16 b1 = *reinterpret_cast<const Vec16*>(patch_bytes + pbase[1] + koff);
-#pragma unroll
-      for (int c = 0; c < CT16; ++c) {
-        const Vec16 af = sW[(16 * c + r) * wrow + kv];
-        acc[c][0] = mma_vec<T>(af, b0, acc[c][0]);
-        acc[c][1] = mma_vec<T>(af, b1, acc[c][1]);
-      }
-    }
-    // ---- epilogue: lane holds couts 16c + 4gq + j of pixel 32wv + 16pt + r
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-      if (pseg[pt] >= 0) {
-        const int wq = pwq[pt];
-        int n, hq0;
-        tile_origin(g, tile, pseg[pt] + sb * g.sub_seg, n, hq0);
-        const int hq = hq0 + pj[pt] + sb * g.sub_j;
-        if (n < g.N && hq < g.Hq && a.y_planes > 0) {
-          // NCHW f32 output with y_planes (<= 16) real channels: the reconstruction layout of the reference
-          if (gq * 4 < a.y_planes) {
-            float* Yp = reinterpret_cast<float*>(a.y);
-            const long hw = (long)a.Ho * a.Wo;
-            const long pix = (long)(hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const int co = 4 * gq + jj;
-              if (co < a.y_planes) {
-                const float v = acc[0][pt][jj] + (a.bias ? a.bias[co] : 0.f);
-                st1[0][jj] += v;
-                st2[0][jj] += v * v;
-                Yp[((long)n * a.y_planes + co) * hw + pix] = v;
-              }
-            }
-          }
-        } else if (n < g.N && hq < g.Hq) {
-          const long obase = ((long)(n * a.Ho + hq * a.SO + P.ph) * a.Wo + (wq * a.SO + P.pw)) * a.Cout;
-#pragma unroll
-          for (int c = 0; c < CT16; ++c) {
-            const int co = 16 * c + 4 * gq;
-            if (co < a.Cout) {
-              float v[4];
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) {
-                v[jj] = acc[c][pt][jj] + (a.bias ? a.bias[co + jj] : 0.f);
-                st1[c][jj] += v[jj];
-                st2[c][jj] += v[jj] * v[jj];
-              }
-              store4v<TO>(Y + obase + co, v, a.accumulate != 0);
-            }
-          }
-        }
-      }
-    }
-   }
-  }
-  if (a.stats) {
-#pragma unroll
-    for (int c = 0; c < CT16; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          st1[c][j] += __shfl_xor(st1[c][j], o, 64);
-          st2[c][j] += __shfl_xor(st2[c][j], o, 64);
-        }
-      }
-    __syncthreads();
-    if (r == 0) {
-#pragma unroll
-      for (int c = 0; c < CT16; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          sStat[wv * 2 * CT + 16 * c + 4 * gq + j] = st1[c][j];
-          sStat[wv * 2 * CT + CT + 16 * c + 4 * gq + j] = st2[c][j];
-        }
-    }
-    __syncthreads();
-    if (t < 2 * CT) {
-      const float s = sStat[t] + sStat[2 * CT + t] + sStat[4 * CT + t] + sStat[6 * CT + t];
-      const int which = t / CT, cl = t - which * CT;
-      const int cs = a.y_planes > 0 ? a.y_planes : a.Cout;      // channel count of the statistics rows
-      if (cl < cs) a.stats[((long)blockIdx.z * gridDim.x + blockIdx.x) * 2 * cs + (long)which * cs + cl] = s;
-    }
-  }
-}
-
-size_t gather2_lds_bytes(const Gather2Args& a, int dt, int CT) {
-  const int VE = dt == DT_F32 ? 4 : 8;
-  const int cin_vecs = a.Cin / VE;
-  size_t worst = 0;
-  for (int p = 0; p < a.nphase; ++p) {
-    const TileGeom& g = a.phases[p].g;
-    const int kvecs = a.phases[p].ntaps * cin_vecs, kvp = (kvecs + 3) & ~3;
-    const size_t b = (size_t)CT * (kvp + 1) * 16 + (size_t)g.segs * g.PR * g.PW * cin_vecs * 16 + (size_t)kvp * 4 + 1024 * 4 + (size_t)8 * CT * 4;
-    if (b > worst) worst = b;
-  }
-  return worst;
-}
-
-template <typename T, typename TO>
-static int launch_gather2_t(const Gather2Args& a, int dt, int gx, hipStream_t s) {
-  int ct16 = (a.Cout + 15) / 16;
-  if (ct16 == 3) ct16 = 4;
-  const size_t lds = gather2_lds_bytes(a, dt, ct16 * 16);
-  dim3 grid(gx, 1, a.nphase), block(256);
-  switch (ct16) {
-    case 1: hipLaunchKernelGGL((gather2_kernel<T, TO, 1>), grid, block, lds, s, a); break;
-    case 2: hipLaunchKernelGGL((gather2_kernel<T, TO, 2>), grid, block, lds, s, a); break;
-    case 3: case 4: hipLaunchKernelGGL((gather2_kernel<T, TO, 4>), grid, block, lds, s, a); break;
-    default: set_error("gather2: Cout=%d too large", a.Cout); return MMVAE_ERR_UNSUPPORTED;
-  }
-
-  int rc = check_launch("gather2");
-  return rc ? rc : gx * a.nphase;
-}
-
-int launch_gather2(int dt, int out_dt, const Gather2Args& a, int gx, hipStream_t s) {
-  if (dt == DT_F32) return launch_gather2_t<float, float>(a, dt, gx, s);
-  if (out_dt == DT_F32) return launch_gather2_t<bf16_t, float>(a, dt, gx, s);
-  return launch_gather2_t<bf16_t, bf16_t>(a, dt, gx, s);
-}
-
-}  // namespace mmvae
-
-namespace mmvae {
 
 // ============================================================================ gather3: barrier-free streaming gather
 // For thin layers (small K, small Cout) LDS staging of the input is pure overhead: no wave shares its pixels with

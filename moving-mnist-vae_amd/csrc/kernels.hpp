@@ -106,17 +106,6 @@ int launch_conv1_bwd_stream(const Conv1BwdLaunch& L, hipStream_t s);  // returns
 struct TileGeom { int N, Hq, Wq, Hi, Wi, SI, oh, ow, segs, qr, PR, PW, tiles_per_img, ntiles, TP, sub, sub_j, sub_seg, sub_pix; };
 bool make_tile_geom(TileGeom& g, int N, int Hq, int Wq, int Hi, int Wi, int SI, int oh, int ow, int span_h, int span_w, int TP = 128,
                     int sub = 1);
-struct Phase2 { TileGeom g; int ph, pw, ntaps, tap0; long w_off; };
-struct Gather2Args {
-  const void* x; const void* w; void* y;
-  const float* pro_scale; const float* pro_shift; int pro_relu;
-  const float* bias; float* stats; int accumulate;
-  int Cin, Cout, Ho, Wo, SO;
-  int nphase; Phase2 phases[kMaxPhases]; Tap taps[kMaxTaps];
-  int x_planar, x_planes, y_planes;
-};
-size_t gather2_lds_bytes(const Gather2Args& a, int dt, int CT);
-int launch_gather2(int dt, int out_dt, const Gather2Args& a, int gx, hipStream_t s);
 struct Wgrad2Args {
   const void* P; const void* G; float* dW;
   const float* proP_scale; const float* proP_shift; int proP_relu;
@@ -245,7 +234,6 @@ int launch_stem_bwd_finalize(const float* partials, int nparts, const double* R,
 int launch_chan_stats_nhwc(int dt, const void* y, long npix, int C, float* partials, hipStream_t s);
 int chan_stats_parts(long npix, int C);
 // same for an NCHW f32 tensor [N][C][HW]
-int launch_chan_stats_nchw(const float* y, int N, int C, int HW, float* partials, hipStream_t s);
 // training finalize: partials -> mean/istd/scale/shift; running stats update (momentum, unbiased var); nbt += 1
 struct BnFinalizeArgs {
   float in_scale = 1.f;      // the statistics are of y' = in_scale * y (fp8 layers: statically scaled weights): eps and the running
@@ -261,8 +249,6 @@ struct BnFoldEntry { int g_off, b_off, rm_off, rv_off, scale_off, shift_off, C; 
 constexpr int kBnFoldMax = 96;                       // 96 x 32 B of kernel arguments per launch
 struct BnFoldTable { BnFoldEntry e[kBnFoldMax]; };
 int launch_bn_fold_eval(const BnFoldEntry* entries, int n, const float* params, const float* bnbuf, float* bnws, float eps, hipStream_t s);
-int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
-                          float* scale, float* shift, hipStream_t s, float in_scale = 1.f);
 // out = relu(a*sa + ba + b*sb + bb)   (NHWC, T)
 int launch_join_fwd(int dt, const void* a, const float* sa, const float* ba, const void* b, const float* sb, const float* bb,
                     void* out, long npix, int C, hipStream_t s);
@@ -299,8 +285,6 @@ int launch_tail_wgrad_finalize(const float* wpartials, int nparts, float* dW, hi
 int launch_tail_join_bwd_apply(int dt, const float* d_raw, const float* w, int OC, int N, int H, int W, const float* ms, const float* mb,
                                const float* ms1, const float* mb1, const void* y0, const float* A0, const float* B0, const float* C0, void* dy0,
                                const void* y1, const float* A1, const float* B1, const float* C1, void* dy1, hipStream_t s);
-int launch_tail_wgrad_tile(int dt, const void* x, const void* x1, const float* ms, const float* mb, const float* ms1, const float* mb1,
-                           const float* d_raw, float* dW, float* scratch, int N, int H, int W, hipStream_t s);
 // last up-block forward: residual join + tail conv in one pass, the joined activation is not stored (bn_elem.hip)
 bool tail_fwd_fusable(int dt, int OC, int N, int H, int W);
 int launch_tail_join_fwd(int dt, const void* y0, const float* ms, const float* mb, const void* y1, const float* ms1, const float* mb1,
@@ -365,6 +349,5 @@ int launch_concat2_to_t(int dt, const float* a, const float* b, int rows, int ca
 int launch_loss_finish(const double* acc, float* out, float nll, float klc, float mmdc, float n, hipStream_t s);
 // out[c] += sum_p partials[p*row_stride + c]  (c < C)
 int launch_partials_add(const float* partials, int nparts, int row_stride, int C, float* out, hipStream_t s);
-int launch_double_to_float(const double* in, float* out, int n, float scale, hipStream_t s);
 
 }  // namespace mmvae

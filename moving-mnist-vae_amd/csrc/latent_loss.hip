@@ -644,13 +644,5 @@ int launch_partials_add(const float* partials, int nparts, int row_stride, int C
   return check_launch("partials_add");
 }
 
-__global__ void d2f_kernel(const double* in, float* out, int n, float scale) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)(in[i] * (double)scale);
-}
-int launch_double_to_float(const double* in, float* out, int n, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(d2f_kernel, dim3((n + 63) / 64), dim3(64), 0, s, in, out, n, scale);
-  return check_launch("d2f");
-}
 
 }  // namespace mmvae

@@ -398,10 +398,10 @@ int Net::fold_bn_eval(int which, const float* params, const float* bnbuf, char* 
   return MMVAE_OK;
 }
 
-int Net::bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s, float in_scale) {
+// eval mode: fold_bn_eval() has written every (scale, shift) pair of the entry point already
+int Net::bn_eval(const Bn&, const float*, const float*, char*, hipStream_t, float) {
   if (eval_folded_) return MMVAE_OK;
-  return launch_bn_eval_affine(params + bn.g_off, params + bn.b_off, bnbuf + bn.rm_off, bnbuf + bn.rv_off, 1e-5f, bn.C,
-                               bnf(bn, base, 2), bnf(bn, base, 3), s, in_scale);
+  set_error("bn_eval: the entry point did not fold its BatchNorms"); return MMVAE_ERR_ARG;
 }
 
 BnBwdFinalizeArgs Net::bwd_finalize_args(const Bn& bn, const float* params, float* grads, char* base, const float* partials, int nparts, int ny,
@@ -942,24 +942,14 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                    bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
   else
     MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
-  // one output plane: a tiled VALU reduction (launch_tail_wgrad_tile) beats the MFMA wgrad
   static const bool tail_fused_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
-  static const bool tail_wg_env = [] { const char* e = getenv("MMVAE_TAIL_WGRAD_IN_REDUCE"); return !(e && e[0] == '0'); }();
   const bool tail_fused = tail_fused_env && !dec.empty() && dec.back().C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
-  // forward did not store the joined activation: the weight gradient recomputes it, inside the join-backward reduce pass (below)
-  // or, MMVAE_TAIL_WGRAD_IN_REDUCE=0, in its own kernel on the side stream
-  const bool tail_wg_in_reduce = tail_fwd_fused() && tail_fused && tail_wg_env;
+  // forward did not store the joined activation: the weight gradient recomputes it inside the join-backward reduce pass (below)
+  const bool tail_wg_in_reduce = tail_fwd_fused() && tail_fused;
   if (store8 && !tail_wg_in_reduce) { set_error("fp8 storage of the last up-block needs the fused tail backward"); return MMVAE_ERR_UNSUPPORTED; }
   if (tail_wg_in_reduce) {
   } else if (tail_fwd_fused()) {
-    const Block& B = dec.back();
-    MM_TRY(side_fork(s));
-    MM_TRY(launch_tail_wgrad_tile(dt(), base + B.y2, base + B.ys, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2), bnf(B.bs, base, 3),
-                                  d_raw, grads + tail.off, wscratch_, N, Sd, Sd, wgrad_stream(s)));
-  } else if (cfg.out_ch == 1 && !dec.empty() && tail_join_fusable(dt(), 1, N, Sd, Sd)) {
-    MM_TRY(side_fork(s));
-    MM_TRY(launch_tail_wgrad_tile(dt(), base + dec.back().out, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, grads + tail.off, wscratch_,
-                                  N, Sd, Sd, wgrad_stream(s)));
+    set_error("decoder_bwd: the fused tail forward (no stored join) needs the fused tail backward (MMVAE_TAIL_FUSED)"); return MMVAE_ERR_UNSUPPORTED;
   } else {
     // dW[oc][ci][kh][kw]: P = d_raw (planar f32, out_ch planes staged as 16 zero-padded channels), G = the last up-block's output
     WgradArgs a; std::memset(&a, 0, sizeof(a));
