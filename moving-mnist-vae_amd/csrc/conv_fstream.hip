@@ -467,7 +467,8 @@ __global__ __launch_bounds__(256, 3) void convT4_stream_kernel(ConvT4StreamArgs 
             }
           }
         }
-        // the finished output row 2*iq + ph leaves as 16 bytes per lane
+        // the finished output row 2*iq + ph leaves as 16 bytes per lane (compiler fence: stored as 4- / 8-byte vectors, read back as 16-byte ones)
+        asm volatile("" ::: "memory");
         char* dst = reinterpret_cast<char*>(a.y) + (((long)n * (2 * a.Hi) + 2 * iq + ph) * (2 * WIN)) * CBO;
 #pragma unroll
         for (int k = 0; k < OROWB / 1024; ++k) *reinterpret_cast<Vec16*>(dst + (lane + 64 * k) * 16) = *reinterpret_cast<const Vec16*>(orow + (lane + 64 * k) * 16);
@@ -528,18 +529,21 @@ __global__ __launch_bounds__(256, 2) void up5_tail_fwd_kernel(Up5TailFwdArgs a) 
       wuA[p][th] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.wu) + p * 2048 + r * 128 + th * 64 + gq * 16);
     }
   const int dwl[2] = {(gq >> 1) ? -1 : 0, (gq >> 1) ? 0 : 1};
-  // tail conv A fragments (as in tail_fwd_stream_kernel): only output row 0 is real
-  Vec16 wT[3][2];
+  // tail conv, per-tap-column form: D[kw][n] = sum_{kh, c} w[c][kh][kw] J[oh - 1 + kh][column n][c] -- rows m = kw (3 of 16 real), K = two
+  // joined rows x 16 channels per MFMA (kh = 0, 1), the third row (kh = 2) in a second MFMA whose upper K half is zero.  Every joined pixel
+  // is read ONCE per output row (2 B-operand reads per 16-pixel tile instead of 6); the three columns a pixel needs are combined across
+  // lanes with DPP row shifts: out[p] = D[0][p - 1] + D[1][p] + D[2][p + 1].
+  Vec16 wT[2];
+  {
+    float f0[8], f1[8];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float f[8];
-      const int kw = 2 * half + (gq >> 1);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const int c = 8 * (gq & 1) + j; f[j] = (r == 0 && kw < 3) ? a.w[c * 9 + kh * 3 + kw] : 0.f; }
-      wT[kh][half] = Elem<bf16_t>::pack(f);
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * (gq & 1) + j;
+      f0[j] = r < 3 ? a.w[c * 9 + (gq >> 1) * 3 + r] : 0.f;                  // k = (kh = gq >> 1, c)
+      f1[j] = (r < 3 && gq < 2) ? a.w[c * 9 + 2 * 3 + r] : 0.f;              // k = (kh = 2, c) in the lower half, zeros above
     }
+    wT[0] = Elem<bf16_t>::pack(f0); wT[1] = Elem<bf16_t>::pack(f1);
+  }
   const float bias = a.bias ? a.bias[0] : 0.f;
   // prologue coefficients of the 8 channels this lane stages per input row; join coefficients of this lane's 4 output channels
   float p1s[8], p1b[8], pxs[8], pxb[8];
@@ -642,33 +646,54 @@ __global__ __launch_bounds__(256, 2) void up5_tail_fwd_kernel(Up5TailFwdArgs a) 
           }
         }
       }
+      // (the joined rows were stored as 8-byte vectors and are read back as 16-byte ones: without a compiler-level fence type-based alias
+      // analysis may hoist those loads above the stores)
+      asm volatile("" ::: "memory");
       // ---- the tail conv's output rows that have all three joined rows now: 2 iq - 1 and 2 iq (inside the strip and the image)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int oh = 2 * iq - 1 + k;
         if (oh < 2 * q0 || oh >= 2 * (q0 + a.HS) || oh < 0 || oh >= H) continue;
         f32x4 acc[4];
+        const char* row01 = ringJ + ((oh - 1 + (gq >> 1) + 8 * NSLOT) % NSLOT) * JROWB;      // this lane's k half: joined row oh - 1 or oh
+        const char* row2 = ringJ + ((oh + 1 + 8 * NSLOT) % NSLOT) * JROWB;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) acc[pt] = (f32x4){0, 0, 0, 0};
+        for (int pt = 0; pt < 4; ++pt) {
+          const int po = (16 * pt + r + 1) * CB + (gq & 1) * 16;                             // column 16 pt + r (ring index + 1: the halo)
+          acc[pt] = mma_bf16(wT[0], *reinterpret_cast<const Vec16*>(row01 + po), (f32x4){0, 0, 0, 0});
+          acc[pt] = mma_bf16(wT[1], *reinterpret_cast<const Vec16*>(row2 + po), acc[pt]);
+        }
+        // lanes gq = 0 hold D[kw = 0..2][column 16 pt + r] in acc[pt][0..2]
+        float d0[4], d1[4], d2[4];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const char* rowp = ringJ + ((oh - 1 + kh + 8 * NSLOT) % NSLOT) * JROWB;
+        for (int pt = 0; pt < 4; ++pt) {
+          d0[pt] = acc[pt][0]; d1[pt] = acc[pt][1]; d2[pt] = acc[pt][2];
+          // (hipcc 7.2 otherwise feeds element 0 to the DPP moves of element 2 as well -- seen in the ISA; pin the three values)
+          asm volatile("" : "+v"(d0[pt]), "+v"(d1[pt]), "+v"(d2[pt]));
+        }
+        float outv[4];
 #pragma unroll
-          for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int pt = 0; pt < 4; ++pt) {
-              const int kw = 2 * half + (gq >> 1);
-              const Vec16 b = *reinterpret_cast<const Vec16*>(rowp + (16 * pt + r + (kw < 3 ? kw : 0)) * CB + (gq & 1) * 16);
-              acc[pt] = mma_bf16(wT[kh][half], b, acc[pt]);
-            }
+        for (int pt = 0; pt < 4; ++pt) {
+          // D[0] of column p - 1: lane r - 1 of this tile, lane 15 of the previous one (or the zero halo column)
+          float left = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d0[pt]), 0x111, 0xf, 0xf, true));          // row_shr:1
+          if (pt > 0) {
+            const float pl = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d0[pt - 1]), 0x121, 0xf, 0xf, true)); // row_ror:1
+            left = r == 0 ? pl : left;
+          }
+          // D[2] of column p + 1: lane r + 1 of this tile, lane 0 of the next one
+          float right = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d2[pt]), 0x101, 0xf, 0xf, true));         // row_shl:1
+          if (pt < 3) {
+            const float nr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d2[pt + 1]), 0x12f, 0xf, 0xf, true)); // row_ror:15
+            right = r == 15 ? nr : right;
+          }
+          outv[pt] = (left + d1[pt]) + right + bias;
         }
         if (gq == 0) {
           float* orow = a.r_raw + ((long)n * H + oh) * W + r;
 #pragma unroll
           for (int pt = 0; pt < 4; ++pt) {
-            const float v = acc[pt][0] + bias;
-            orow[16 * pt] = v;
-            st1 += v; st2 += v * v;
+            orow[16 * pt] = outv[pt];
+            st1 += outv[pt]; st2 += outv[pt] * outv[pt];
           }
         }
       }
