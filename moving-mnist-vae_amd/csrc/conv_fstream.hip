@@ -228,18 +228,19 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamAr
     if (lane < 2) *reinterpret_cast<Vec16*>(ring + s * ROWB + lane * 16) = Vec16{{0, 0, 0, 0}};
     else if (lane < 4) *reinterpret_cast<Vec16*>(ring + s * ROWB + (WL - 1) * CB + (lane - 2) * 16) = Vec16{{0, 0, 0, 0}};
   }
-  // A fragments: only output row 0 is real.  K-step (kh, 0): taps (kh,0),(kh,1); K-step (kh, 1): tap (kh,2) and a zero tap
-  Vec16 wA[KS][2];
+  // A fragments, per-tap-column form (see up5_tail_fwd_kernel): D[kw][column] over two joined rows per MFMA (kh = 0, 1) + the third row
+  // (kh = 2) in a second one; rows m = kw, every joined pixel is read once per output row
+  Vec16 wA[2];
+  {
+    float f0[8], f1[8];
 #pragma unroll
-  for (int kh = 0; kh < KS; ++kh)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float f[8];
-      const int kw = 2 * half + (gq >> 1);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const int c = 8 * (gq & 1) + j; f[j] = (r == 0 && kw < KS) ? a.w[c * 9 + kh * 3 + kw] : 0.f; }
-      wA[kh][half] = Elem<bf16_t>::pack(f);
+    for (int j = 0; j < 8; ++j) {
+      const int c = 8 * (gq & 1) + j;
+      f0[j] = r < 3 ? a.w[c * 9 + (gq >> 1) * 3 + r] : 0.f;
+      f1[j] = (r < 3 && gq < 2) ? a.w[c * 9 + 2 * 3 + r] : 0.f;
     }
+    wA[0] = Elem<bf16_t>::pack(f0); wA[1] = Elem<bf16_t>::pack(f1);
+  }
   const float bias = a.bias ? a.bias[0] : 0.f;
   // join coefficients of the 8 channels this lane stages (vector lane + 64k of a row: channels 8 * (lane & 1) ..)
   float c2s[NC], c2b[NC], css[NC];
@@ -308,29 +309,39 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_stream_kernel(TailFwdStreamAr
     __builtin_amdgcn_sched_barrier(0);
     if (q >= NPRIME) {
       const int n = u / nstrips, oh = (u - n * nstrips) * a.HS + q - NPRIME;
-      f32x4 acc[4];
+      const char* row01 = ring + ((oh - 1 + (gq >> 1) + 4 * NSLOT) % NSLOT) * ROWB;       // this lane's k half: joined row oh - 1 or oh
+      const char* row2 = ring + ((oh + 1 + 4 * NSLOT) % NSLOT) * ROWB;
+      float d0[4], d1[4], d2[4];
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) acc[pt] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-      for (int kh = 0; kh < KS; ++kh) {
-        const char* rowp = ring + ((oh - 1 + kh + 4 * NSLOT) % NSLOT) * ROWB;
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-          for (int pt = 0; pt < 4; ++pt) {
-            // k = 8gq ..: tap kw = 2*half + (gq >> 1) (kw = 3: the A fragment is zero there; the read stays inside the row), channels 8*(gq & 1) ..
-            const int kw = 2 * half + (gq >> 1);
-            const Vec16 b = *reinterpret_cast<const Vec16*>(rowp + (16 * pt + r + (kw < KS ? kw : 0)) * CB + (gq & 1) * 16);
-            acc[pt] = mma_bf16(wA[kh][half], b, acc[pt]);
-          }
+      for (int pt = 0; pt < 4; ++pt) {
+        const int po = (16 * pt + r + 1) * CB + (gq & 1) * 16;                             // column 16 pt + r (ring index + 1: the halo)
+        f32x4 acc = mma_bf16(wA[0], *reinterpret_cast<const Vec16*>(row01 + po), (f32x4){0, 0, 0, 0});
+        acc = mma_bf16(wA[1], *reinterpret_cast<const Vec16*>(row2 + po), acc);
+        d0[pt] = acc[0]; d1[pt] = acc[1]; d2[pt] = acc[2];
+        asm volatile("" : "+v"(d0[pt]), "+v"(d1[pt]), "+v"(d2[pt]));                       // (pinned: see up5_tail_fwd_kernel)
       }
-      if (gq == 0) {                                                        // D row 0 lives in lanes gq = 0, element 0: pixel 16pt + r
+      // lanes gq = 0: out[p] = D[0][p - 1] + D[1][p] + D[2][p + 1], neighbours through DPP row shifts (tile edges from the adjacent tile)
+      float outv[4];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        float left = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d0[pt]), 0x111, 0xf, 0xf, true));          // row_shr:1
+        if (pt > 0) {
+          const float pl = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d0[pt - 1]), 0x121, 0xf, 0xf, true)); // row_ror:1
+          left = r == 0 ? pl : left;
+        }
+        float right = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d2[pt]), 0x101, 0xf, 0xf, true));         // row_shl:1
+        if (pt < 3) {
+          const float nr = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d2[pt + 1]), 0x12f, 0xf, 0xf, true)); // row_ror:15
+          right = r == 15 ? nr : right;
+        }
+        outv[pt] = (left + d1[pt]) + right + bias;
+      }
+      if (gq == 0) {
         float* orow = a.r_raw + ((long)n * a.H + oh) * W + r;
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-          const float v = acc[pt][0] + bias;
-          orow[16 * pt] = v;
-          st1 += v; st2 += v * v;
+          orow[16 * pt] = outv[pt];
+          st1 += outv[pt]; st2 += outv[pt] * outv[pt];
         }
       }
     }
