@@ -183,6 +183,48 @@ def test_train_loop_trajectory_matches_reference(name, dt, oracle, pkg):
     assert len(st) == len(list(m.parameters())) and set(st[0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["c1_gauss", "gauss_s28", "gauss_rgb"])
+def test_eval_mode_forward_matches_oracle(name, dt, oracle):
+    """model.eval() forward (the reference's plotting branch, main.py:401-424: encoder AND decoder with the running statistics, every
+    BatchNorm folded to scale / shift in one launch per entry point) against the oracle in eval mode, after one training step has moved the
+    running statistics away from their defaults."""
+    O = oracle
+    g, cfg = load(name)
+    n, z, S = cfg["N"], cfg["z"], cfg["S"]
+    dev = torch.device("cuda")
+    m, spec = build_model(cfg, dt, O)
+    labels, image, categorical, target = case_inputs(O, cfg, int(g["labels_seed"]))
+    eps = torch.from_numpy(g["eps"]).view(n, z, 1, 1)
+    m.injected_eps = eps.to(dev)
+    m.injected_true_samples = torch.from_numpy(g["true_samples"]).to(dev)
+    mu, lv, enc, rec = m(image.to(dev))                       # one training forward: running statistics updated
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    m.injected_eps = eps.to(dev)
+    with torch.no_grad():
+        mu, lv, enc, rec = m(image.to(dev))
+    torch.cuda.synchronize()
+    omu, olv, oenc, orec = O.vae_forward(sd, image, eps, S, False, True)
+    t = TOL[dt]
+    assert (mu.cpu() - omu).abs().max().item() <= t["lat"], "mu"
+    assert (lv.cpu() - olv).abs().max().item() <= t["lat"], "logvar"
+    # (one step has moved the running statistics only a tenth of the way to the batch's: the eval-mode activations are O(10) and not
+    # re-normalised layer by layer, so the reconstruction is compared relative to its own range; bf16 in relative L2)
+    rc, scale = rec.cpu(), orec.abs().max().item()
+    rel_max = (rc - orec).abs().max().item() / scale
+    rel_l2 = (rc - orec).norm().item() / orec.norm().item()
+    print(f"\neval forward {name} {dt}: recon max-abs error / range {rel_max:.2e}, rel-L2 {rel_l2:.2e} (range {scale:.1f})")
+    if dt == "f32":
+        assert rel_max <= 2e-5, rel_max          # measured 1.4e-6 .. 3.0e-6
+    else:
+        assert rel_l2 <= 8e-2, rel_l2            # measured 2.9e-2 .. 3.9e-2
+    # the statistics are untouched by an eval forward
+    sd2 = m.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(sd2[k].cpu(), v), k
+
+
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_bf16_gradient_noise_not_worse_than_torch_autocast(name, oracle):
     O = oracle
