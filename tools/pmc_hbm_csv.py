@@ -37,7 +37,7 @@ def last_step(rows):
 def pick(step):
     names = [n for n, _ in step]
     out = {"__step__": sum(v for _, v in step)}
-    j = next(i for i, n in enumerate(names) if "tail_join_fwd_kernel" in n or "tail_fwd_stream_kernel" in n)
+    j = next(i for i, n in enumerate(names) if "tail_join_fwd_kernel" in n or "tail_fwd_stream_kernel" in n or "up5_tail_fwd_kernel" in n)
     conv = "convT4_stream_kernel" if any("convT4_stream_kernel" in n for n in names[:j]) else "patch_conv_kernel"
     i = max(k for k in range(j) if conv in names[k])
     out["uplayer5.conv2.fwd"] = step[i][1]
