@@ -219,6 +219,12 @@ MMVAE_API int mmvae_conv2d_dgrad(int dtype, int transposed, const void* dy, cons
 MMVAE_API int mmvae_conv2d_wgrad(int dtype, int transposed, const void* x, const void* dy, float* dweight, int N, int H, int W, int Cin,
                        int Cout, int k, int stride, int pad, const float* pro_scale, const float* pro_shift, int pro_relu,
                        void* scratch, void* stream);
+/* Weight gradients of a residual block's conv1 (Conv2d 3x3 stride 2 pad 1) AND of its 1x1 stride-2 shortcut conv from ONE pass over their
+ * common input x (encoder.layer1, model.py:29,135-138): dweight [Cout][Cin][3][3] += dy^T (x) x taps, dweight_sc [Cout][Cin][1][1] += dy_sc^T (x) x.
+ * bf16, 32 -> 32 channels, 32x32 -> 16x16 (MMVAE_ERR_UNSUPPORTED otherwise); pro_*: BatchNorm+ReLU applied to x on load; scratch as above. */
+MMVAE_API int mmvae_conv2d_wgrad_pair(int dtype, const void* x, const void* dy, const void* dy_shortcut, float* dweight, float* dweight_sc, int N,
+                            int H, int W, int Cin, int Cout, const float* pro_scale, const float* pro_shift, int pro_relu, void* scratch,
+                            void* stream);
 /* ---- BatchNorm2d in training mode and the 1-channel stem, op level (what a maintainer binds instead of torch.nn.BatchNorm2d,
  * model.py:14,20,30,95,..., and of encoder.conv1 + encoder.bn1, model.py:94-95,103)
  * Tensors are NHWC [npix][C] of `dtype`; statistics, parameters and their gradients are f32.

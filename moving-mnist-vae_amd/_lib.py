@@ -54,6 +54,7 @@ PROTOTYPES = {
     "mmvae_conv2d_fwd": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P]),
     "mmvae_conv2d_dgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "mmvae_conv2d_wgrad": (c_int, [c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "mmvae_conv2d_wgrad_pair": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P]),
     "mmvae_rbf_kernel": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "mmvae_comm_unique_id": (c_int, [P]),
     "mmvae_comm_init": (c_int, [POINTER(c_void_p), c_int, c_int, P]),

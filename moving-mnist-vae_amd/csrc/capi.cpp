@@ -308,6 +308,15 @@ int mmvae_conv2d_wgrad(int dt, int transposed, const void* x, const void* dy, fl
   if (!transposed) return op_run_wgrad(dt, g, N, dy, Ho, Wo, nullptr, nullptr, 0, x, H, W, ps, pb, relu, dw, S(st), sc);
   return op_run_wgrad(dt, g, N, x, H, W, ps, pb, relu, dy, Ho, Wo, nullptr, nullptr, 0, dw, S(st), sc);
 }
+int mmvae_conv2d_wgrad_pair(int dt, const void* x, const void* dy, const void* dy_sc, float* dw, float* dw_sc, int N, int H, int W, int Cin, int Cout,
+                            const float* ps, const float* pb, int relu, void* scratch, void* st) {
+  if (!scratch || !x || !dy || !dy_sc || !dw || !dw_sc || N < 1) { set_error("conv2d_wgrad_pair: bad argument"); return MMVAE_ERR_ARG; }
+  const ConvGeom g = geom_for(0, Cin, Cout, 3, 2, 1), gs = geom_for(0, Cin, Cout, 1, 2, 0);
+  const int Ho = out_size(0, H, 3, 2, 1), Wo = out_size(0, W, 3, 2, 1);
+  const int rc = op_run_wgrad_pair(dt, g, gs, N, dy, dy_sc, Ho, Wo, x, H, W, ps, pb, relu, dw, dw_sc, S(st), static_cast<float*>(scratch), 1.f, 1.f);
+  if (rc == 0) { set_error("conv2d_wgrad_pair: shape not supported (bf16, 32 -> 32 channels, 32x32 -> 16x16)"); return MMVAE_ERR_UNSUPPORTED; }
+  return rc < 0 ? rc : MMVAE_OK;
+}
 int mmvae_convT_bwd_fused(int dt, const void* x, const void* dy, const float* w, float* dw, void* dx, int N, int H, int W, int Cin, int Cout, int k,
                           int s, int p, const float* ps, const float* pb, int relu, const void* x2, const float* w2, float* dw2, void* scratch,
                           void* wscratch, void* st) {

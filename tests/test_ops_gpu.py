@@ -221,3 +221,38 @@ if __name__ == "__main__":
                     bad += 1
                     print(dt, pro, cfg, "EXCEPTION", repr(ex)[:300], flush=True)
     print("FAILURES:", bad)
+
+
+@pytest.mark.parametrize("N", [2, 37])
+@pytest.mark.parametrize("prologue", [False, True])
+def test_conv_wgrad_pair_one_pass(N, prologue):
+    """mmvae_conv2d_wgrad_pair (wgrad_stream_kernel with the centre-tap companion): the weight gradients of encoder.layer1's conv1 (3x3 s2 p1,
+    32 -> 32) and of its 1x1 stride-2 shortcut from ONE pass over the block input, against torch fp32 on the same bf16-rounded operands
+    (model.py:29,135-138)."""
+    L = _lib()
+    lib = L.lib()
+    g = torch.Generator().manual_seed(4000 + N)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(torch.randn(N, 32, 32, 32, generator=g))
+    ps = pb = None
+    xin = x
+    if prologue:
+        ps = torch.rand(32, generator=g) + 0.5
+        pb = torch.randn(32, generator=g) * 0.3
+        xin = bf(F.relu(x * ps.view(1, -1, 1, 1) + pb.view(1, -1, 1, 1)))
+    w1 = torch.zeros(32, 32, 3, 3, requires_grad=True)
+    ws = torch.zeros(32, 32, 1, 1, requires_grad=True)
+    dy1, dys = bf(torch.randn(N, 32, 16, 16, generator=g)), bf(torch.randn(N, 32, 16, 16, generator=g))
+    F.conv2d(xin, w1, None, 2, 1).backward(dy1)
+    F.conv2d(xin, ws, None, 2, 0).backward(dys)
+    xd, d1, d2 = _to_dev(x, "bf16"), _to_dev(dy1, "bf16"), _to_dev(dys, "bf16")
+    dw1 = torch.zeros(32, 32, 3, 3, device="cuda")
+    dws = torch.zeros(32, 32, 1, 1, device="cuda")
+    psd = ps.cuda() if prologue else None
+    pbd = pb.cuda() if prologue else None
+    L.check(lib.mmvae_conv2d_wgrad_pair(1, L.ptr(xd), L.ptr(d1), L.ptr(d2), L.ptr(dw1), L.ptr(dws), N, 32, 32, 32, 32, L.ptr(psd), L.ptr(pbd), 1,
+                                        L.ptr(_wgrad_scratch()), torch.cuda.current_stream().cuda_stream), "conv2d_wgrad_pair")
+    torch.cuda.synchronize()
+    e1 = ((dw1.cpu() - w1.grad).abs().max() / w1.grad.abs().max()).item()
+    es = ((dws.cpu() - ws.grad).abs().max() / ws.grad.abs().max()).item()
+    assert e1 < 2e-4 and es < 2e-4, (N, prologue, e1, es)
