@@ -289,6 +289,15 @@ int mmvae_conv2d_dgrad(int dt, int transposed, const void* dy, const float* w, v
   const ConvGeom g = geom_for(transposed, Cin, Cout, k, s, p);
   const int Ho = out_size(transposed, H, k, s, p), Wo = out_size(transposed, W, k, s, p);
   SecondSrc q;
+  if (!transposed && s == 1 && conv3_stream_ok(dt, Cin, Cout, k, s, p, H, W)) {
+    // encoder.layer1.conv2's shape: the data gradient as a forward conv over dy with the weights packed [cin][flipped tap][cout]
+    PackArgs pf; std::memset(&pf, 0, sizeof(pf));
+    pf.src = w; pf.dst = scratch; pf.cols = Cin; pf.K = Cout; pf.ntaps = 9; pf.s_col = 9; pf.s_k = Cin * 9; pf.scale = 1.f;
+    for (int t = 0; t < 9; ++t) pf.tap_off[t] = 8 - t;
+    int rc = launch_pack(dt, pf, S(st)); if (rc < 0) return rc;
+    rc = launch_conv3_stream(dt, 1, dy, scratch, nullptr, dx, nullptr, nullptr, nullptr, 0, nullptr, nullptr, N, H, S(st));
+    return rc < 0 ? rc : MMVAE_OK;
+  }
   if (!transposed) {
     q.wfrag = op_frag_up(dt, g, H, W);
     int rc = op_pack_up(dt, g, w, scratch, S(st), 1.f, 0, q.wfrag); if (rc < 0) return rc;

@@ -22,13 +22,17 @@ struct Conv3StreamArgs {
   const void* x; const void* w; const void* wsc; void* y; void* ysc;
   const float* pro_scale; const float* pro_shift; int pro_relu;
   float* stats; float* stats_sc;          // partial rows [blocks][2][32] (nullable)
+  // BS (a data gradient run as a forward conv over dy): `stats` receives the BatchNorm-BACKWARD sums of the BatchNorm + ReLU that produced
+  // this conv's output side in the forward pass: rows [sum g, sum g * ym] with g = the (bf16-rounded) result masked by ym * ms + mb > 0
+  const void* ym; const float* ms; const float* mb;
   int N, Ho, Hi;
   int HS, nunits;                         // output rows per strip, N * Ho / HS
 };
 
 // S: stride (1 or 2); SC: also the 1x1 stride-S shortcut (second weight set, second output); 32 -> 32 channels, 16 output columns
-template <int S, bool SC, bool PRO>
+template <int S, bool SC, bool PRO, bool BS = false>
 __global__ __launch_bounds__(256, 2) void conv3_stream_kernel(Conv3StreamArgs a) {
+  static_assert(!BS || (S == 1 && !SC && !PRO), "backward sums: the stride-1 data gradient");
   constexpr int KS = 3, PAD = 1, WO = 16, WI = S * WO, CB = 64;            // bytes per pixel (32 channels of bf16)
   constexpr int WL = WI + 2;                                                // ring row: one zero pixel on each side
   constexpr int ROWB = WL * CB;
@@ -61,6 +65,12 @@ __global__ __launch_bounds__(256, 2) void conv3_stream_kernel(Conv3StreamArgs a)
     for (int j = 0; j < 8; ++j) { psc[j] = a.pro_scale[c + j]; psh[j] = a.pro_shift[c + j]; }
   }
   const float lo = a.pro_relu ? 0.f : -__builtin_inff();
+  float bms[8], bmb[8];
+  if (BS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bms[j] = a.ms[8 * gq + j]; bmb[j] = a.mb[8 * gq + j]; }
+  }
+  Vec16 yv = Vec16{{0, 0, 0, 0}};
   float st[SC ? 4 : 2][8];
 #pragma unroll
   for (int q = 0; q < (SC ? 4 : 2); ++q)
@@ -90,6 +100,8 @@ __global__ __launch_bounds__(256, 2) void conv3_stream_kernel(Conv3StreamArgs a)
       xv[k] = Vec16{{0, 0, 0, 0}};
       if (row >= 0 && row < a.Hi) xv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(X) + (((long)n * a.Hi + row) * WI) * CB + off);
     }
+    if (BS && q >= NPRIME)     // the mask / sum operand of the output row this step computes: this lane's 8 channels of pixel r
+      yv = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.ym) + ((((long)n * a.Ho + oh0 + q - NPRIME) * WO + r) * 32 + 8 * gq) * 2);
   };
   auto commit = [&](int u, int q) {
     const int n = u / nstrips, oh0 = (u - n * nstrips) * a.HS;
@@ -116,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv3_stream_kernel(Conv3StreamArgs a)
   if (u < u_end) issue(u, 0);
   while (u < u_end) {
     commit(u, q);
+    const Vec16 ycur = yv;                                                  // (BS) loaded for THIS step by the previous issue
     int un = u, qn = q + 1;
     if (qn == nq) { un = u + u_step; qn = 0; }
     if (un < u_end) issue(un, qn);
@@ -140,8 +153,19 @@ __global__ __launch_bounds__(256, 2) void conv3_stream_kernel(Conv3StreamArgs a)
       const long po = (((long)n * a.Ho + oh) * WO + r) * 32 + 8 * gq;
       {
         const float v[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+        if constexpr (BS) {
+          float ym[8], vr[8];
+          Elem<bf16_t>::unpack(ycur, ym);
+          Elem<bf16_t>::unpack(Elem<bf16_t>::pack(v), vr);                // the gradient as the stored tensor holds it
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { st[0][j] += v[j]; st[1][j] += v[j] * v[j]; }
+          for (int j = 0; j < 8; ++j) {
+            const float g = (ym[j] * bms[j] + bmb[j] > 0.f) ? vr[j] : 0.f;
+            st[0][j] += g; st[1][j] += g * ym[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { st[0][j] += v[j]; st[1][j] += v[j] * v[j]; }
+        }
         dstore8<bf16_t>(reinterpret_cast<bf16_t*>(a.y) + po, v, false);
       }
       if constexpr (SC) {
@@ -199,6 +223,24 @@ int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const 
 #undef MMVAE_C3
   note_launch_bytes((double)N * 32 * 2.0 * ((double)a.Hi * a.Hi + (double)Ho * Ho * (wsc ? 2 : 1)));
   const int rc = check_launch("conv3_stream");
+  return rc ? rc : gx;
+}
+
+// The data gradient of a 3x3 stride-1 32 -> 32 Conv2d as a forward conv over dy (w: the conv's weights packed [cin][flipped tap][cout]) with
+// the backward sums of the BatchNorm + ReLU in front of that conv from the same pass (rows [sum g][sum g * ym], g masked by ym * ms + mb > 0):
+// encoder.layer1.conv2's dgrad and bn1's reduce in one kernel.  Returns the number of partial rows (> 0) or an error.
+int launch_conv3_stream_bwd(int dt, const void* dy, const void* w_flipped, void* dx, const void* ym, const float* ms, const float* mb, float* sums,
+                            int N, int H, hipStream_t s) {
+  if (dt != DT_BF16 || H != 16 || !ym || !ms || !mb || !sums) { set_error("conv3_stream_bwd: bf16, 16x16 maps, mask operand and sums required"); return MMVAE_ERR_UNSUPPORTED; }
+  Conv3StreamArgs a; memset(&a, 0, sizeof(a));
+  a.x = dy; a.w = w_flipped; a.y = dx; a.stats = sums; a.ym = ym; a.ms = ms; a.mb = mb; a.N = N; a.Ho = H; a.Hi = H;
+  a.HS = 8; a.nunits = N * (H / a.HS);
+  int gx = 768;
+  while (gx > 8 && (long)gx * 4 > a.nunits) gx -= 8;
+  const size_t lds = 2048 + 4 * (size_t)(4 * 18 * 64);
+  hipLaunchKernelGGL((conv3_stream_kernel<1, false, false, true>), dim3(gx), dim3(256), lds, s, a);
+  note_launch_bytes((double)N * 32 * 2.0 * 3.0 * H * H);
+  const int rc = check_launch("conv3_stream_bwd");
   return rc ? rc : gx;
 }
 

@@ -204,6 +204,8 @@ bool stem_bwd_fusable(int S);
 // 32 -> 32 channel 3x3 forward convs on 16-pixel-wide output maps as a per-wave stream, optionally with the block's 1x1 stride-2 shortcut
 // from the same input rows (conv_fstream.hip): returns stats rows (> 0) or an error
 bool conv3_stream_ok(int dt, int Cin, int Cout, int k, int s, int p, int Hin, int Win);
+int launch_conv3_stream_bwd(int dt, const void* dy, const void* w_flipped, void* dx, const void* ym, const float* ms, const float* mb, float* sums,
+                            int N, int H, hipStream_t s);
 int launch_conv3_stream(int dt, int stride, const void* x, const void* w, const void* wsc, void* y, void* ysc, const float* pro_scale,
                         const float* pro_shift, int pro_relu, float* stats, float* stats_sc, int N, int Ho, hipStream_t s);
 // ConvTranspose2d(16 -> 16, k4 s2 p1) forward on 16x16 / 32x32 inputs as a per-wave stream (conv_fstream.hip)

@@ -102,6 +102,7 @@ Net::Net(const NetCfg& c) : cfg(c) {
   head_pack_lv = n_packed; n_packed += hp;
   head_pack_dg = n_packed; n_packed += align_up(2L * c.z * 256, 8);
   stem_pack = n_packed; n_packed += 32L * 25 * 8;
+  l1c2_flip = n_packed; n_packed += 32L * 9 * 32;          // encoder.layer1.conv2 as [cin][flipped tap][cout]: its data gradient as a forward conv
   tail_pack_f = n_packed; n_packed += 16L * 9 * 16;
   tail_pack_d = n_packed; n_packed += 16L * 9 * 8;
   // ---- decoder (model.py:154-179)
@@ -341,6 +342,14 @@ static bool wgrad_pair_ok(int dt, const ConvGeom& g, const ConvGeom& gs, int Hou
          gs.D1 == 32 && Hout == 16 && Hin == 32;
 }
 
+// encoder.layer1.conv2's data gradient + bn1's backward sums in one stream pass (bf16, 32 -> 32 channels, 16x16 maps, one block per stage)
+bool Net::l1_dgrad_stream() const {
+  static const bool env = [] { const char* e = getenv("MMVAE_L1_DGRAD_STREAM"); return !(e && e[0] == '0'); }();
+  if (!env || enc.empty()) return false;
+  const Block& B = enc[0];
+  return !B.identity && !B.c2.fp8 && conv3_stream_ok(dt(), B.C, B.C, B.c2.k, B.c2.s, B.c2.p, B.Hout, B.Wout);
+}
+
 bool Net::tail_fwd_fused() const {
   static const bool env = [] { const char* e = getenv("MMVAE_TAIL_FWD_FUSED"); return !(e && e[0] == '0'); }();
   static const bool bwd_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
@@ -487,6 +496,15 @@ int Net::packs_enc_bwd(const float* params, char* base, hipStream_t s) {
     MM_TRY(pack_up(B.c2, params, base, s));
     MM_TRY(pack_up(B.c1, params, base, s));
     if (!B.identity) MM_TRY(pack_up(B.cs, params, base, s));
+  }
+  if (l1_dgrad_stream()) {
+    // dx[n,h,w,ci] = sum_{kh,kw,co} dy[n, h+1-kh, w+1-kw, co] W[co][ci][kh][kw]: a forward 3x3 conv over dy with weights [ci][tap' = 8 - tap][co]
+    const ConvW& w = enc[0].c2;
+    PackArgs pf; std::memset(&pf, 0, sizeof(pf));
+    pf.src = params + w.off; pf.dst = base + P.packed + l1c2_flip * (long)esz();
+    pf.cols = 32; pf.K = 32; pf.ntaps = 9; pf.s_col = 9; pf.s_k = 32 * 9; pf.scale = w.wscale;
+    for (int t = 0; t < 9; ++t) pf.tap_off[t] = 8 - t;
+    MM_TRY(launch_pack(dt(), pf, s));
   }
   return MMVAE_OK;
 }
@@ -710,6 +728,8 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // conv2 (3x3 s1): wgrad with a1 = relu(bn1(y1)) recomputed in the load prologue; dgrad -> d_a1
     hipStream_t wsm = wgrad_stream(s);
     MM_TRY(side_fork(s));
+    // (measured and not kept: a THIRD stream for this block's two weight-gradient kernels, so that they need not wait for the side stream's
+    // backlog of deeper layers -- 6.93-6.96 against 6.96 ms per step, within the run-to-run spread)
     // encoder.layer1 (the block the step ends on): conv2's partial images go to the second scratch (idle in this pass) and are reduced
     // AFTER the block's other weight gradient has been enqueued -- under the stem backward's load a 19 MB reduce takes 120 us instead of
     // 10, and it sat in front of the last big kernel of the side stream
@@ -723,9 +743,15 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // (encoder.layer1: the shortcut's weight gradient rides on conv1's pass over the block input, below)
     const bool pair = !B.identity && !B.c1.fp8 && !B.cs.fp8 && wgrad_pair_ok(dt(), geom(B.c1), geom(B.cs), B.Hout, B.Hin);
     if (!B.identity && !pair) MM_TRY(run_wgrad(B.cs, N, base + dyso, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
-    MM_TRY(run_up(B.c2, base, N, base + dy2o, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
-    // bn1 + relu backward
-    np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
+    if (i == 0 && l1_dgrad_stream()) {
+      // encoder.layer1.conv2: the data gradient as a per-wave stream over dy2 (conv3_stream_kernel) with bn1's backward sums from the same pass
+      np = launch_conv3_stream_bwd(dt(), base + dy2o, base + plan_.packed + l1c2_flip * (long)esz(), base + P.da1, base + B.y1, bnf(B.b1, base, 2),
+                                   bnf(B.b1, base, 3), part, N, B.Hout, s);
+    } else {
+      MM_TRY(run_up(B.c2, base, N, base + dy2o, B.Hout, B.Wout, base + P.da1, B.Hout, B.Wout, nullptr, nullptr, 0, nullptr, 0, s));
+      // bn1 + relu backward
+      np = launch_bn_bwd_reduce(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, nullptr, npix, B.C, part, s);
+    }
     MM_TRY(np);
     MM_TRY(bn_backward_coefs(B.b1, params, grads, base, np, 1, 0, cnt, s));
     MM_TRY(launch_bn_bwd_apply(dt(), base + P.da1, nullptr, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + B.y1, bnf(B.b1, base, 4),

@@ -163,6 +163,8 @@ class Net {
   int bn_eval(const Bn& bn, const float* params, const float* bnbuf, char* base, hipStream_t s, float in_scale = 1.f);
   // eval mode: all BatchNorms of the encoder (which = 0) / decoder (1) folded to (scale, shift) in one launch; bn_eval() is then a no-op
   int fold_bn_eval(int which, const float* params, const float* bnbuf, char* base, hipStream_t s);
+  bool l1_dgrad_stream() const;
+  long l1c2_flip = 0;
   bool eval_folded_ = false;
   bool store8 = false;          // fp8 mode: the last up-block's branch outputs are stored as e4m3 bytes (see the constructor)
   float* bnf(const Bn& bn, char* base, int which) const;   // 0 mean 1 istd 2 scale 3 shift 4 A 5 B 6 C
