@@ -184,7 +184,6 @@ def _time_calls(fn, reps, warm=2):
 # encoder.layer1's 3x3 convs on wgrad_stream_kernel, the stem / tail / heads on their own kernels):
 # name, transposed, Cin, Cout, k, stride, pad, H (input side of the forward op), BatchNorm+ReLU prologue on x
 WGRAD2_LAYERS = [
-    ("encoder.layer1.0.downsample.0", 0, 32, 32, 1, 2, 0, 32, 1),
     ("encoder.layer2.0.conv1", 0, 32, 64, 3, 2, 1, 16, 0), ("encoder.layer2.0.conv2", 0, 64, 64, 3, 1, 1, 8, 1),
     ("encoder.layer2.0.downsample.0", 0, 32, 64, 1, 2, 0, 16, 0),
     ("encoder.layer3.0.conv1", 0, 64, 128, 3, 2, 1, 8, 0), ("encoder.layer3.0.conv2", 0, 128, 128, 3, 1, 1, 4, 1),
@@ -202,7 +201,7 @@ WGRAD2_LAYERS = [
 
 def dominant_kernel_roofline(M, device, N, reps=10):
     """`roofline`: the kernel family with the most GPU time per step in the committed kernel statistics (profiles/*_top_kernels.json) is
-    wgrad2_kernel, the weight gradient of the channel-heavy layers (20 launches, side stream).  Every layer that runs on it is timed
+    wgrad2_kernel, the weight gradient of the channel-heavy layers (19 launches, side stream).  Every layer that runs on it is timed
     in isolation through the C ABI (mmvae_conv2d_wgrad: kernel + partial-image reduce, events on the launch stream), the SLOWEST one is
     the family's largest instance and is reported against the roofline that bounds it: algorithmic bytes = x + dy (bf16) + the weight
     gradient (f32), flops = 2 * pixels * Cin * Cout * k^2; bound = mfma when flops / bytes exceeds the bf16 ridge (2.5 PF / 8 TB/s)."""
@@ -241,9 +240,10 @@ def dominant_kernel_roofline(M, device, N, reps=10):
     mfma_bound = flop / alg > MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
     top = committed_top_kernels(N)
     fam = None if top is None else next((f for f in top["families"] if f["family"] == "wgrad2_kernel"), None)
+    traffic, tsrc = pmc_traffic(f"wgrad2.{name}", N)       # kernel + its partial-image reduce inside the step (tools/pmc_hbm_csv.py)
     return {"bound": "mfma" if mfma_bound else "hbm", "achieved": tfs if mfma_bound else gbs, "peak": MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tfs / MFMA_PEAK_TFLOPS) if mfma_bound else (gbs / HBM_PEAK_GBS),
-            "traffic": None, "traffic_source": None,
+            "traffic": traffic, "traffic_source": tsrc,
             "kernel": f"wgrad2_kernel (+ wgrad_reduce_kernel) @ {name}: weight gradient of {'ConvTranspose2d' if tr else 'Conv2d'}({Cin} -> {Cout}, k{k} s{sd} p{p}) "
                       f"on {H}x{H} inputs, the slowest of the {len(WGRAD2_LAYERS)} layers of the step's largest kernel family by GPU time "
                       "(isolated mmvae_conv2d_wgrad calls: tap-split MFMA tiles, per-block partial images, ordered reduce)",
