@@ -262,8 +262,6 @@ __global__ void row_sqnorm_kernel(const float* __restrict__ x, int n, int d, flo
   if (lane == 0) out[row] = a;
 }
 
-// (round 3, measured and not kept: 128 x 128 tiles -- a wave owns a 64 x 64 quadrant, 48 MFMAs per staged 32-k chunk instead of 12 -- are SLOWER,
-// 128 us against 112, 123 with the next chunk's loads in flight during the MFMAs: neither the barrier count nor the load latency is the limit)
 // Persistent MFMA kernel.  The work list holds only the 64 x 64 tiles that count: the symmetric xx / yy sums pair tile row p
 // with row tiles-1-p (tiles+1 upper-triangle entries per pair), xy takes the full square; a block walks the list with stride
 // gridDim.x and issues ONE double atomic at the end (one per tile serialised 12.9 k same-address atomics at N = 5120).
