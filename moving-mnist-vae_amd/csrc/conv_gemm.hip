@@ -556,6 +556,23 @@ static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   return launch_deep2_conv(dt, out_dt, b, gx, s);
 }
 
+// pos_conv_kernel (conv_pos.inc): q-grids up to 4x4, MFMA columns = images, padded (position, tap) pairs not computed.  MMVAE_POS=0: off
+static int try_pos(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
+  static const int enabled = [] { const char* e = getenv("MMVAE_POS"); return e ? atoi(e) : 1; }();
+  if (!enabled || conv_force_v1() || dt != DT_BF16 || out_dt != DT_BF16 || !a.wfrag || a.fp8 || a.gup == 0) return 0;
+  if (a.x_planar || a.y_planes || a.x2 || a.bias || a.Hi != a.Wi || a.Ho != a.Wo || a.Cout % 32 != 0) return 0;
+  const int up = a.gup == 2 ? 1 : 0;
+  if (!pos_conv_takes(a.gk, a.gs, a.gp, up, a.Hi, a.Ho, a.Cin)) return 0;
+  if (up && a.gs > 1 && a.gk < a.gs && !a.accumulate) return 0;      // stride phases without a tap would have to be zero-filled
+  if ((long)a.N * a.Ho * a.Wo * a.Cout >= (1L << 32)) return 0;
+  PosArgs b; memset(&b, 0, sizeof(b));
+  b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
+  b.stats = a.stats; b.accumulate = a.accumulate; b.N = a.N; b.Cout = a.Cout;
+  b.nw = a.Cout / 32 < 8 ? a.Cout / 32 : 8;
+  if ((a.Cout / 32) % b.nw != 0 || (64 * b.nw) % (a.Cin / 8) != 0) return 0;
+  return launch_pos_conv(a.gk, a.gs, a.gp, up, a.Hi, a.Ho, a.Cin, b, s);
+}
+
 // the second source as its own accumulate launch (shapes the patch-tile kernel does not merge)
 static int launch_x2_separately(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   GatherArgs b; memset(&b, 0, sizeof(b));
@@ -565,6 +582,7 @@ static int launch_x2_separately(int dt, int out_dt, const GatherArgs& a, hipStre
   b.x = a.x2; b.w = a.w2; b.y = a.y; b.accumulate = 1; b.wfrag = a.wfrag2;
   b.N = a.N; b.Hi = Hq; b.Wi = Wq; b.Cin = a.Cin2; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = 1; b.SO = a.SO;
   b.nphase = 1; b.phases[0] = Phase{a.x2_ph, a.x2_pw, Hq, Wq, 1, 0, 0}; b.taps[0] = Tap{0, 0};
+  b.gk = 1; b.gs = a.SO; b.gp = 0; b.gup = 2;      // a 1x1 stride-SO transposed conv into phase (0, 0)
   return launch_gather_gemm(dt, out_dt, b, s);
 }
 
@@ -615,6 +633,8 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
   if (!conv_force_v1()) {
     const int rcp = a.wfrag ? 0 : try_patch(dt, out_dt, a, s);
     if (rcp != 0) return rcp;
+    const int rcq = try_pos(dt, out_dt, a, s);
+    if (rcq != 0) return rcq;
     const int rcd2 = try_deep2(dt, out_dt, a, s);
     if (rcd2 != 0) return rcd2;
     if (a.wfrag) { set_error("gather_gemm: fragment-major weights (Cin=%d Cout=%d) need the deep2 kernel, which does not take this launch", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }

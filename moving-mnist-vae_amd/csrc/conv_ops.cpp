@@ -97,6 +97,7 @@ int op_run_down(int dt, int out_dt, const ConvGeom& g, const void* packed, int N
   a.x = L; a.w = packed; a.y = S;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hl; a.Wi = Wl; a.Cin = g.D1; a.Ho = Hs; a.Wo = Ws; a.Cout = g.D0; a.SI = g.s; a.SO = 1;
+  a.gk = g.k; a.gs = g.s; a.gp = g.p; a.gup = 1;
   a.nphase = 1;
   a.phases[0] = Phase{0, 0, Hs, Ws, g.k * g.k, 0, 0};
   for (int kh = 0; kh < g.k; ++kh)
@@ -113,6 +114,7 @@ int op_run_up(int dt, const ConvGeom& g, const void* packed, int N, const void* 
   a.x = S; a.w = packed; a.y = L;
   a.pro_scale = pro_s; a.pro_shift = pro_b; a.pro_relu = relu; a.stats = stats; a.accumulate = accumulate;
   a.N = N; a.Hi = Hs; a.Wi = Ws; a.Cin = g.D0; a.Ho = Hl; a.Wo = Wl; a.Cout = g.D1; a.SI = 1; a.SO = g.s;
+  a.gk = g.k; a.gs = g.s; a.gp = g.p; a.gup = 2;
   UpPhase ph[4];
   const int np = up_phases(g.k, g.s, g.p, ph);
   long off = 0; int tap0 = 0; a.nphase = 0;

@@ -37,7 +37,8 @@ struct GatherArgs {
   // (3x3 / 4x4 main path + 1x1 shortcut) into one kernel: no read-modify-write of the sum.
   const void* x2; const void* w2; int Cin2, x2_ph, x2_pw;
   int fp8;                 // 1: w holds e4m3 bytes (same [cout][tap][cin] order); only the deep-layer kernel takes it (else an error)
-  int wfrag, wfrag2;       // 1: w (w2) is packed fragment-major (PackArgs::frag); only deep2_conv_kernel reads it (else an error)
+  int wfrag, wfrag2;       // 1: w (w2) is packed fragment-major (PackArgs::frag); only deep2_conv_kernel / pos_conv_kernel read it (else an error)
+  int gk, gs, gp, gup;     // the conv-like weight's (k, s, p) and the form (1: down, 2: up) when the launch comes from op_run_down / op_run_up (0: unknown)
 };
 // Shapes deep2_conv_kernel takes (conv_deep2.inc): the layers whose weights are packed fragment-major.  q grid Hq x Wq per phase
 // and image, input map Hi x Wi, ntaps over all phases.
@@ -175,6 +176,20 @@ size_t deep_conv_lds_bytes(const DeepArgs& a, int dt);
 int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
 size_t deep2_conv_lds_bytes(const DeepArgs& a, int dt);
 int launch_deep2_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);  // conv_deep2.inc; returns stats rows (= gx) or <0
+// ---- position-major implicit GEMM for q-grids up to 4x4 (conv_pos.inc; bf16, fragment-major weights): an MFMA column is an image, so
+// (position, tap) pairs that fall into the zero padding are not computed at all
+struct PosArgs {
+  const void* x; const void* w; void* y;
+  const float* pro_scale; const float* pro_shift; int pro_relu;
+  float* stats; int accumulate;
+  int N, Cout;
+  int nw;                      // waves per block (32 couts each); grid.y = Cout / (32 nw)
+  int ntiles;                  // set by the launcher
+};
+// up = 0: "down" form (Conv2d forward / ConvT data gradient), up = 1: "up" form; HI / HO input / output map size.  Returns stats rows (> 0),
+// 0 when no instantiation takes the geometry, < 0 on error.
+int launch_pos_conv(int K, int S, int P, int up, int HI, int HO, int CIN, const PosArgs& a, hipStream_t s);
+bool pos_conv_takes(int K, int S, int P, int up, int HI, int HO, int CIN);
 bool conv_force_v1();
 int conv_xcd_walk();      // MMVAE_XCD (default 1): XCD-aware tile order in the persistent patch-tile kernels   // MMVAE_CONV_V1=1 forces the generic v1 kernels (A/B and coverage)
 

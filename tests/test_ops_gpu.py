@@ -40,6 +40,10 @@ CONFIGS = [
     (32, 16, 3, 1, 1, 0, 32, 3), (16, 16, 4, 2, 1, 0, 64, 2),
     (32, 16, 4, 2, 1, 1, 32, 5), (16, 16, 4, 2, 1, 1, 32, 70),                                   # streaming weight gradient (32x32 -> 64x64)
     (32, 32, 3, 2, 1, 0, 32, 3), (32, 32, 3, 1, 1, 0, 16, 5), (32, 32, 3, 2, 1, 0, 32, 41),      # streaming 3x3 forward (encoder.layer1)
+    # position-major kernel (conv_pos.inc): several 16 / 32 / 64-image tiles with a ragged last one
+    (128, 128, 3, 1, 1, 0, 4, 37), (256, 256, 3, 1, 1, 0, 2, 70), (128, 256, 3, 2, 1, 0, 4, 45), (64, 128, 3, 2, 1, 0, 8, 19),
+    (128, 128, 4, 2, 1, 1, 2, 50), (128, 64, 4, 2, 1, 1, 4, 21), (64, 64, 4, 2, 1, 1, 4, 33), (128, 256, 1, 2, 0, 0, 4, 40),
+    (128, 128, 1, 1, 0, 0, 2, 41), (128, 64, 1, 1, 0, 0, 4, 18), (128, 128, 2, 2, 0, 1, 1, 100),
 ]
 
 
