@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (MMVAE_LIB_PATH: developer A/B runs of two builds on one box; the product always loads the in-tree library)
 LIB_PATH = os.environ.get("MMVAE_LIB_PATH") or os.path.join(_HERE, "libmmvae_hip.so")
 _lib = None
+ABI_VERSION = 3            # MMVAE_ABI_VERSION of include/mmvae.h
 
 P = c_void_p
 
@@ -103,6 +104,11 @@ def lib():
         fn = getattr(l, name)
         fn.restype = res
         fn.argtypes = args
+    # include/mmvae.h: "bindings check mmvae_abi_version() at load time" -- a stale or foreign build would be called with shifted arguments
+    got = l.mmvae_abi_version()
+    if got != ABI_VERSION:
+        raise MmvaeError(f"{LIB_PATH} has C ABI version {got}, this binding expects {ABI_VERSION}: rebuild the library "
+                         "(make -C moving-mnist-vae_amd/csrc)")
     _lib = l
     return l
 

@@ -564,6 +564,7 @@ static int try_pos(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   const int up = a.gup == 2 ? 1 : 0;
   if (!pos_conv_takes(a.gk, a.gs, a.gp, up, a.Hi, a.Ho, a.Cin)) return 0;
   if (up && a.gs > 1 && a.gk < a.gs && !a.accumulate) return 0;      // stride phases without a tap would have to be zero-filled
+  if (a.Hi >= 8 && a.Cout < 128) return 0;      // an 8x8 input tile is 131 KB of LDS (one block per CU): with two waves per block deep2 wins (measured)
   if ((long)a.N * a.Ho * a.Wo * a.Cout >= (1L << 32)) return 0;
   PosArgs b; memset(&b, 0, sizeof(b));
   b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;

@@ -11,7 +11,7 @@ int pos_conv_tu_a(int K, int S, int P, int up, int HI, int HO, int CIN, const Po
   POS_CASE(3, 1, 1, true, 2, 2, 256, 2)
   POS_CASE(3, 1, 1, true, 2, 2, 128, 2)
   POS_CASE(3, 2, 1, false, 4, 2, 128, 2)      // encoder.layer4.conv1
-  POS_CASE(3, 2, 1, false, 8, 4, 64, 1)       // encoder.layer3.conv1
+  // (encoder.layer3.conv1, 8x8x64 -> 4x4: a 16-image tile is 131 KB of LDS, one block per CU -- deep2_conv_kernel is faster: 28 vs 31 us)
   POS_CASE(3, 2, 1, true, 2, 4, 256, 2)       // their data gradients
   POS_CASE(3, 2, 1, true, 4, 8, 128, 1)
   return 0;

@@ -9,7 +9,6 @@ static int pos_conv_tu_c(int K, int S, int P, int up, int HI, int HO, int CIN, c
   POS_CASE(1, 1, 0, false, 4, 4, 128, 1)      // decoder.uplayer2.conv1
   POS_CASE(1, 1, 0, false, 4, 4, 64, 1)       // its data gradient
   POS_CASE(1, 2, 0, false, 4, 2, 128, 2)      // encoder.layer4.downsample
-  POS_CASE(1, 2, 0, false, 8, 4, 64, 1)       // encoder.layer3.downsample
   POS_CASE(1, 2, 0, true, 2, 4, 256, 2)       // their data gradients (accumulating launches: only phase (0, 0) has a tap)
   POS_CASE(1, 2, 0, true, 4, 8, 128, 1)
   return 0;

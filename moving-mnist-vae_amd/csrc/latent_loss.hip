@@ -512,8 +512,7 @@ int launch_adam_dev(const AdamArgs& a, double* state, hipStream_t s) {
 // Four labels per thread (32-byte / 4-byte loads, 16-byte f32 store, 8-byte bf16 store); TL = int64 (what the reference's loader yields)
 // or uint8 (a label transport an eighth of the size); both outputs optional.
 template <typename T, typename TL>
-__global__ void normalise_kernel(const TL* __restrict__ labels, long n, float mean, float stdv, T* __restrict__ img, float* __restrict__ img32) {
-  const long nq = n >> 2;
+__global__ void normalise_kernel(const TL* __restrict__ labels, long n, long nq, float mean, float stdv, T* __restrict__ img, float* __restrict__ img32) {
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
     float v[4];
     if constexpr (sizeof(TL) == 8) {
@@ -541,13 +540,18 @@ __global__ void normalise_kernel(const TL* __restrict__ labels, long n, float me
 int launch_normalise(int dt, const void* labels, int label_bytes, long n, float mean, float stdv, void* img_t, float* img_f32, hipStream_t s) {
   if (n <= 0) return MMVAE_OK;
   if (label_bytes != 8 && label_bytes != 1) { set_error("normalise: labels must be int64 or uint8"); return MMVAE_ERR_ARG; }
-  const dim3 g(rblocks((n >> 2) + 1, 2048)), b(256);
+  // the vector path needs 16-byte (int64) / 4-byte (uint8) aligned labels and 16- / 8-byte aligned outputs: a contiguous but misaligned
+  // view (labels[1:], an odd uint8 offset) takes the scalar loop for the whole range
+  const bool aligned = reinterpret_cast<uintptr_t>(labels) % (label_bytes == 8 ? 16 : 4) == 0 && reinterpret_cast<uintptr_t>(img_f32) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(img_t) % (dt == DT_F32 ? 16 : 8) == 0;
+  const long nq = aligned ? n >> 2 : 0;
+  const dim3 g(rblocks(aligned ? (n >> 2) + 1 : n, 2048)), b(256);
   if (label_bytes == 8) {
-    if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float, long long>), g, b, 0, s, (const long long*)labels, n, mean, stdv, (float*)img_t, img_f32);
-    else hipLaunchKernelGGL((normalise_kernel<bf16_t, long long>), g, b, 0, s, (const long long*)labels, n, mean, stdv, (bf16_t*)img_t, img_f32);
+    if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float, long long>), g, b, 0, s, (const long long*)labels, n, nq, mean, stdv, (float*)img_t, img_f32);
+    else hipLaunchKernelGGL((normalise_kernel<bf16_t, long long>), g, b, 0, s, (const long long*)labels, n, nq, mean, stdv, (bf16_t*)img_t, img_f32);
   } else {
-    if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float, unsigned char>), g, b, 0, s, (const unsigned char*)labels, n, mean, stdv, (float*)img_t, img_f32);
-    else hipLaunchKernelGGL((normalise_kernel<bf16_t, unsigned char>), g, b, 0, s, (const unsigned char*)labels, n, mean, stdv, (bf16_t*)img_t, img_f32);
+    if (dt == DT_F32) hipLaunchKernelGGL((normalise_kernel<float, unsigned char>), g, b, 0, s, (const unsigned char*)labels, n, nq, mean, stdv, (float*)img_t, img_f32);
+    else hipLaunchKernelGGL((normalise_kernel<bf16_t, unsigned char>), g, b, 0, s, (const unsigned char*)labels, n, nq, mean, stdv, (bf16_t*)img_t, img_f32);
   }
   return check_launch("normalise");
 }

@@ -65,7 +65,7 @@ class _EncoderFn(torch.autograd.Function):
         ws = model._workspace(N, training)
         # prepare_batch staged this very tensor (same storage, untouched since) into this workspace: no conversion pass over x
         st_ = model._staged
-        staged = st_ is not None and st_[0] == x.data_ptr() and st_[1] == x._version and st_[2] == ws.data_ptr() and st_[3] == N
+        staged = st_ is not None and st_[0]() is x and st_[1] == x._version and st_[2] == ws.data_ptr() and st_[3] == N
         model._staged = None
         fn = lib().mmvae_encoder_fwd_staged if staged else lib().mmvae_encoder_fwd
         check(fn(model._h, N, ptr(x), model._net_ptr(model._flat), ptr(model._bnf), ptr(model._bni), ptr(ws), ws.numel(),
@@ -400,7 +400,8 @@ class VAE(nn.Module):
         d["_sync"] = None
         d["_last_scalars"] = None
         d["_last_group"] = None
-        d["_staged"] = None                # (image data_ptr, version, workspace data_ptr, N) of the batch prepare_batch staged
+        d["_staged"] = None                # (weakref to the image prepare_batch staged, its version, workspace data_ptr, N)
+        d["_grad_key"] = None
         d["_last_recon"] = None            # (data_ptr, forward stamp) of the last train-mode reconstruction
         d["_pending_tail"] = None          # Gaussian loss gradient handed from _LossFn.backward to _DecoderFn.backward
         d["_nan_scalar"] = None
@@ -630,10 +631,21 @@ class VAE(nn.Module):
 
     def _grad_target(self):
         """Flat gradient buffer to write into: buffer 0 normally; buffer 1 when .grad tensors already exist
-        (so that autograd's accumulation into them stays correct)."""
-        p0 = self._ptable[0][1]
+        (so that autograd's accumulation into them stays correct).  The choice is keyed on the parameter whose .grad autograd
+        writes LAST in a backward pass -- the encoder's first parameter (the PixelCNN's when there is no encoder): its .grad does not change
+        between the backward nodes of one pass (PixelCNN -> decoder -> encoder), so all of them pick the same buffer."""
+        key = self._grad_key
+        if key is None:
+            key = self._ptable[0][1]
+            if self._h is not None:
+                for e in self._ptable:
+                    if e[2] == self._poff:
+                        key = e[1]
+                        break
+            self.__dict__["_grad_key"] = key
         idx = 0
-        if p0.grad is not None and self._G[0] is not None and p0.grad.data_ptr() == self._G[0].data_ptr():
+        if key.grad is not None and self._G[0] is not None and \
+                self._G[0].data_ptr() <= key.grad.data_ptr() < self._G[0].data_ptr() + 4 * self._n_params:
             idx = 1
         if self._G[idx] is None or self._G[idx].device != self._flat.device:
             self._G[idx] = torch.zeros(self._n_params, dtype=torch.float32, device=self._flat.device)
@@ -770,12 +782,20 @@ class VAE(nn.Module):
         N = labels.numel() // (S * S * self.in_channels)
         image = torch.empty((N, self.in_channels, S, S), device=labels.device, dtype=torch.float32)
         self._ensure_flat()
-        # one pass: the f32 image (network input, Gaussian target) and its storage-type copy straight into the workspace the forward
-        # pass is about to use (train() calls the model right after; _EncoderFn checks that it really is this tensor, unmodified)
-        ws = self._workspace(N, bool(self.training))
-        check(lib().mmvae_net_stage_labels(self._h, N, ptr(labels), labels.element_size(), float(data_mean), float(data_std), ptr(image), ptr(ws),
-                                           ws.numel(), _stream()), "mmvae_net_stage_labels")
-        self.__dict__["_staged"] = (image.data_ptr(), image._version, ws.data_ptr(), N)
+        if self._h is None:
+            # a PixelCNN on its own (main.py:50-58 "pixelcnn_N"): no encoder workspace to stage into, the f32 image only
+            if labels.dtype != torch.int64:
+                labels = labels.long()
+            check(lib().mmvae_normalise_labels(ptr(labels), image.numel(), float(data_mean), float(data_std), ptr(image), _stream()),
+                  "mmvae_normalise_labels")
+            self.__dict__["_staged"] = None
+        else:
+            # one pass: the f32 image (network input, Gaussian target) and its storage-type copy straight into the workspace the forward
+            # pass is about to use (train() calls the model right after; _EncoderFn checks that it really is this tensor object, unmodified)
+            ws = self._workspace(N, bool(self.training))
+            check(lib().mmvae_net_stage_labels(self._h, N, ptr(labels), labels.element_size(), float(data_mean), float(data_std), ptr(image), ptr(ws),
+                                               ws.numel(), _stream()), "mmvae_net_stage_labels")
+            self.__dict__["_staged"] = (weakref.ref(image), image._version, ws.data_ptr(), N)
         if categorical:
             target = labels.view(-1, S, S)
             if target.dtype != torch.int64:

@@ -165,6 +165,59 @@ def test_prepare_batch_stages_the_input_once(pkg, oracle):
 
 
 @pytest.mark.gpu
+def test_prepare_batch_identity_and_alignment(pkg, oracle):
+    """The staged-input shortcut is keyed on the tensor OBJECT (a weak reference), not on (pointer, version): a fresh tensor that happens to
+    get the freed image's block back from the caching allocator is converted like any other input.  Label pointers need no alignment:
+    labels[1:] of an int64 batch (8-byte aligned) and an odd uint8 offset normalise to the same values as the aligned copy."""
+    M = importlib.import_module("moving-mnist-vae_amd.model")
+    L = importlib.import_module("moving-mnist-vae_amd._lib")
+    dev = torch.device("cuda")
+    labels = oracle.synthetic_labels(4, 64, seed=9).view(4, 4096)
+    torch.manual_seed(2)
+    m = M.VAE(1, 32, 1, 2, 32, False, False, compute_dtype="bf16").to(dev).train()
+    m.injected_eps = torch.randn(4, 32, 1, 1, device=dev)
+    image, _ = m.prepare_batch(labels, dev, oracle.DATA_MEAN, oracle.DATA_STD, False)
+    ptr0 = image.data_ptr()
+    ref = [t.detach().clone() for t in m(image.clone())]
+    image, _ = m.prepare_batch(labels, dev, oracle.DATA_MEAN, oracle.DATA_STD, False)
+    del image                                            # the staged tensor dies; its block goes back to the allocator
+    other = torch.empty((4, 1, 64, 64), device=dev)      # ... and most likely comes back here
+    other.copy_(ref[0].new_zeros(()).expand_as(other) + 0.25)
+    out = m(other)
+    exp = m(torch.full((4, 1, 64, 64), 0.25, device=dev))
+    for a, b in zip(out, exp):
+        assert torch.equal(a, b), ("the forward ran on a stale staged copy", other.data_ptr() == ptr0)
+    # misaligned label views
+    lib = L.lib()
+    flat = labels.to(dev).view(-1)
+    st = torch.cuda.current_stream().cuda_stream
+    for lab in (flat[1:4097 + 4096], flat.to(torch.uint8)[3:4096 + 3]):
+        n = lab.numel()
+        assert lab.data_ptr() % 16 != 0
+        img = torch.empty(n, device=dev)
+        if lab.dtype == torch.int64:
+            L.check(lib.mmvae_normalise_labels(L.ptr(lab), n, float(oracle.DATA_MEAN), float(oracle.DATA_STD), L.ptr(img), st), "normalise")
+            assert torch.equal(img, (lab.float() - oracle.DATA_MEAN) / oracle.DATA_STD) or \
+                (img - (lab.float() - oracle.DATA_MEAN) / oracle.DATA_STD).abs().max().item() <= 1e-6
+
+
+def test_binding_checks_the_abi_version(pkg):
+    """include/mmvae.h asks bindings to compare mmvae_abi_version() with MMVAE_ABI_VERSION at load time: _lib.lib() does."""
+    import re
+    L = importlib.import_module("moving-mnist-vae_amd._lib")
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mmvae.h")).read()
+    assert int(re.search(r"#define MMVAE_ABI_VERSION (\d+)", hdr).group(1)) == L.ABI_VERSION
+    lib = L.lib()
+    assert lib.mmvae_abi_version() == L.ABI_VERSION
+    saved, L._lib, L.ABI_VERSION = L._lib, None, L.ABI_VERSION + 1
+    try:
+        with pytest.raises(L.MmvaeError):
+            L.lib()
+    finally:
+        L._lib, L.ABI_VERSION = saved, L.ABI_VERSION - 1
+
+
+@pytest.mark.gpu
 def test_moving_mnist_clips_loader(pkg, tmp_path):
     """npz on disk -> device-resident clips -> batches of k-means labels shaped like the reference loader's (B, C*H*W)."""
     rng = np.random.default_rng(1)
