@@ -920,6 +920,8 @@ int launch_wgrad(int dt, WgradArgs a, hipStream_t s) {
   {
     const int rcs = try_wgrad_stream(dt, a, s);
     if (rcs != 0) return rcs < 0 ? rcs : MMVAE_OK;
+    const int rcp = try_wgrad_pos(dt, a, s);
+    if (rcp != 0) return rcp < 0 ? rcp : MMVAE_OK;
     const int rc2 = try_wgrad2(dt, a, s);
     if (rc2 != 0) return rc2 < 0 ? rc2 : MMVAE_OK;
     if (a.P_planar || a.G_planar) { set_error("wgrad: planar operands need the patch-tile kernel"); return MMVAE_ERR_UNSUPPORTED; }

@@ -68,6 +68,7 @@ struct WgradArgs {
                                    // launch took another kernel and reduced at once) -- the caller launches it later, off the busy phase
 };
 int launch_wgrad(int dt, WgradArgs a, hipStream_t s);
+int try_wgrad_pos(int dt, const WgradArgs& a, hipStream_t s);     // conv_wpos.hip: both maps 1x1 .. 4x4 (1 = taken, 0 = not this kernel's shape)
 bool wgrad_stream_shape(int dt, const WgradArgs& a);
 int try_wgrad_stream(int dt, const WgradArgs& a, hipStream_t s);   // conv_wstream.hip: 1 = taken, 0 = not this kernel's shape, <0 error
 int try_wgrad_stream_pair(int dt, const WgradArgs& a, const void* P2, float* dW2, float scale2, hipStream_t s);

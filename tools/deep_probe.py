@@ -1,5 +1,5 @@
 """Developer tool (GPU box): every channel-heavy (Cin, Cout >= 64) convolution of the config-2 network timed in isolation through the
-C ABI (forward and data gradient), with its FLOP count and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak.
+C ABI (forward, data gradient and weight gradient incl. its ordered reduce), with its FLOP count and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak.
 usage: python tools/deep_probe.py [N=5120] [reps=20]"""
 import ctypes
 import importlib
@@ -62,7 +62,16 @@ def main(N=5120, reps=20):
                                         P(scratch.data_ptr()), P(s))
             L.check(rc, name)
 
-        for op, fn in (("fwd", fwd), ("dgrad", dgrad)):
+        dw = torch.zeros_like(w)
+        wsc = main.wsc if hasattr(main, "wsc") else torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        main.wsc = wsc
+
+        def wgrad(pack):
+            rc = lib.mmvae_conv2d_wgrad(1, tr, P(x.data_ptr()), P(y.data_ptr()), P(dw.data_ptr()), N, H, H, Cin, Cout, k, st, p, P(sc.data_ptr()),
+                                        P(sh.data_ptr()), 1, P(wsc.data_ptr()), P(s))
+            L.check(rc, name)
+
+        for op, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
             fn(True)
             fn(op == "dgrad")
             torch.cuda.synchronize()
