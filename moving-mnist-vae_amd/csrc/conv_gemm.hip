@@ -252,13 +252,11 @@ static int launch_gather_t(GatherArgs& a, int gx, hipStream_t s) {
 }
 
 int conv_xcd_walk() {
-  // not cached: developer sweeps (tools/sweep_env.sh) flip it between processes only, but reading it is cheap
-  const char* e = getenv("MMVAE_XCD");
-  return (e && e[0] == '0') ? 0 : 1;
+  return 1;      // XCD-aware tile order (measured neutral to slightly positive; the switch is gone)
 }
 
 bool conv_force_v1() {
-  static const int v = [] { const char* e = getenv("MMVAE_CONV_V1"); return (e && e[0] == '1') ? 1 : 0; }();
+  constexpr int v = 0;
   return v != 0;
 }
 
@@ -287,7 +285,7 @@ constexpr size_t kV2MaxLds = 60 * 1024;
 // Pipelined all-phases patch kernel: eligible when the weights of every phase together with one patch fit LDS.
 // Returns >0 (stats rows) when it ran, 0 when not eligible, <0 on error.
 static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
-  static const int enabled = [] { const char* e = getenv("MMVAE_PATCH"); return e ? atoi(e) : 1; }();
+  constexpr int enabled = 1;
   if (!enabled || a.Cout > 64 || a.Cin > 256) return 0;
   if (a.x2 && (a.x_planar || a.y_planes || a.accumulate || out_dt != dt || a.Cin2 % (dt == DT_F32 ? 4 : 8) != 0 || a.Cin2 > 128 || a.Cout > 32)) return 0;
   if ((long)a.N * a.Ho * a.Wo * (a.y_planes ? a.y_planes : a.Cout) >= (1L << 30)) return 0;     // 32-bit output offsets
@@ -395,7 +393,7 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
   if (gx >= 8) gx &= ~7;
   b.xcd_walk = conv_xcd_walk();
-  { const char* e = getenv("MMVAE_DBG"); b.dbg = e ? atoi(e) : 0; }
+  b.dbg = 0;
   b.x_bytes = a.x_planar ? 0u : (unsigned)((long)a.N * a.Hi * a.Wi * a.Cin * (long)dtype_size(dt));
   if (a.x2) {
     if (ct16 > 2) return 0;
@@ -405,54 +403,9 @@ static int try_patch(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   return launch_patch_conv(dt, out_dt, b, gx, s);
 }
 
-// Deep-layer implicit GEMM (conv_deep.inc): channel-heavy layers on small feature maps, whole images per tile.
-// Returns >0 (stats rows) when it ran, 0 when not eligible, <0 on error.
-static int try_deep(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
-  static const int enabled = [] { const char* e = getenv("MMVAE_DEEP"); return e ? atoi(e) : 1; }();
-  if (!enabled || a.x_planar || a.y_planes) return 0;
-  const int VE = dt == DT_F32 ? 4 : 8;
-  if (a.Cin < 64 || a.Cin % (8 * VE) != 0 || a.Cout < 64 || a.Cout % 64 != 0) return 0;
-  const int cin_vecs = a.Cin / VE;
-  if (512 % cin_vecs != 0) return 0;
-  if ((long)a.N * a.Ho * a.Wo * a.Cout >= (1L << 32)) return 0;
-  DeepArgs b; memset(&b, 0, sizeof(b));
-  b.x = a.x; b.w = a.w; b.y = a.y; b.pro_scale = a.pro_scale; b.pro_shift = a.pro_shift; b.pro_relu = a.pro_relu;
-  b.bias = a.bias; b.stats = a.stats; b.accumulate = a.accumulate;
-  b.N = a.N; b.Hi = a.Hi; b.Wi = a.Wi; b.Cin = a.Cin; b.Ho = a.Ho; b.Wo = a.Wo; b.Cout = a.Cout; b.SI = a.SI; b.SO = a.SO;
-  b.nphase = a.nphase; b.fp8 = a.fp8;
-  for (int p = 0; p < a.nphase; ++p) {
-    const Phase& ph = a.phases[p];
-    if (ph.ntaps <= 0) return 0;
-    b.phases[p] = DeepPhase{ph.ph, ph.pw, ph.Hq, ph.Wq, ph.ntaps, ph.tap0, ph.w_off};
-    b.Hq = ph.Hq > b.Hq ? ph.Hq : b.Hq; b.Wq = ph.Wq > b.Wq ? ph.Wq : b.Wq;
-    b.ntaps_all = ph.tap0 + ph.ntaps > b.ntaps_all ? ph.tap0 + ph.ntaps : b.ntaps_all;
-  }
-  if (b.ntaps_all > kMaxTaps) return 0;
-  for (int t = 0; t < kMaxTaps; ++t) b.taps[t] = a.taps[t];
-  b.ct16 = a.Cout >= 128 ? 8 : 4;
-  const int gy = (a.Cout + b.ct16 * 16 - 1) / (b.ct16 * 16);
-  const int wp = 8 / (b.ct16 / 4);
-  const int hw = b.Hq * b.Wq;
-  bool ok = false;
-  for (int npt = b.ct16 == 8 ? 4 : 2; npt >= 1 && !ok; npt >>= 1) {
-    const int TPX = wp * npt * 16;
-    if (hw > TPX) break;
-    b.npt = npt; b.ipt = TPX / hw;
-    if (b.ipt > a.N) b.ipt = a.N;
-    if (b.ipt * a.Hi * a.Wi >= 65535) continue;
-    b.ntiles = (a.N + b.ipt - 1) / b.ipt;
-    if (npt > 1 && (long)b.ntiles * gy < 256 && a.N * hw > 256 * (TPX / 2)) continue;     // keep every CU busy when the problem allows
-    ok = deep_conv_lds_bytes(b, dt) <= 150 * 1024;
-  }
-  if (!ok) return 0;
-  int gx = b.ntiles < 512 ? b.ntiles : 512;
-  if (gx > kGatherMaxGridX) gx = kGatherMaxGridX;
-  return launch_deep_conv(dt, out_dt, b, gx, s);
-}
-
 // deep2_conv_kernel (conv_deep2.inc): weights from L2 straight into MFMA fragments, no barrier in the K loop.  MMVAE_DEEP2=0: off
 static bool deep2_enabled() {
-  static const int enabled = [] { const char* e = getenv("MMVAE_DEEP2"); return e ? atoi(e) : 1; }();
+  constexpr int enabled = 1;
   return enabled != 0 && !conv_force_v1();
 }
 // LDS bytes of a tile of npt*16 q-pixels (whole images)
@@ -599,9 +552,7 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
     const int rc2 = try_deep2(dt, out_dt, a, s);
     if (rc2 != 0) return rc2;
     if (a.wfrag) { set_error("gather_gemm: fragment-major fp8 weights (Cin=%d Cout=%d) need the deep2 kernel", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }
-    const int rc = try_deep(dt, out_dt, a, s);
-    if (rc == 0) { set_error("gather_gemm: fp8 layer Cin=%d Cout=%d is not eligible for the deep-layer kernel", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }
-    return rc;
+    set_error("gather_gemm: fp8 layer Cin=%d Cout=%d is not eligible for the deep-layer kernel", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED;
   }
   if (a.x2) {
     // fragment-major weights are read by deep2_conv_kernel only, which takes one source: two launches then
@@ -639,13 +590,11 @@ int launch_gather_gemm(int dt, int out_dt, GatherArgs a, hipStream_t s) {
     const int rcd2 = try_deep2(dt, out_dt, a, s);
     if (rcd2 != 0) return rcd2;
     if (a.wfrag) { set_error("gather_gemm: fragment-major weights (Cin=%d Cout=%d) need the deep2 kernel, which does not take this launch", a.Cin, a.Cout); return MMVAE_ERR_UNSUPPORTED; }
-    const int rcd = try_deep(dt, out_dt, a, s);
-    if (rcd != 0) return rcd;
   }
   {
     // thin layers: barrier-free streaming kernel (weights in LDS, pixels straight from global memory)
     constexpr int g3_maxk = 160;
-    static const int g3_dbg = [] { const char* e = getenv("MMVAE_DBG"); return e ? atoi(e) : 0; }();
+    constexpr int g3_dbg = 0;
     a.dbg = g3_dbg;
     int maxk = 0;
     for (int p = 0; p < a.nphase; ++p) if (a.phases[p].ntaps * a.Cin > maxk) maxk = a.phases[p].ntaps * a.Cin;
@@ -889,7 +838,7 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   if (gx > b.g.ntiles) gx = b.g.ntiles;
   if (gx >= 8) gx &= ~7L;
   b.xcd_walk = conv_xcd_walk();
-  { const char* e = getenv("MMVAE_DBG"); b.dbg = e ? atoi(e) : 0; }
+  b.dbg = 0;
   if (partial) { b.dW = a.scratch; b.partial = 1; }
   const int rc = launch_wgrad2(dt, b, (int)gx, tiles_ab, zg, ta16, tb16, s);
   if (rc < 0) return rc;

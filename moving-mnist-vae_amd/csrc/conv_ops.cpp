@@ -66,7 +66,7 @@ int op_pack_up(int dt, const ConvGeom& g, const float* w, void* dst, hipStream_t
 
 // MMVAE_DEEP2_FRAG=0: keep the row-major [cout][tap][cin] packing for deep2_conv_kernel too (A/B of the layout; both are read correctly)
 static bool frag_enabled() {
-  static const bool v = [] { const char* e = getenv("MMVAE_DEEP2_FRAG"); return !(e && e[0] == '0'); }();
+  constexpr bool v = true;
   return v;
 }
 // does deep2_conv_kernel take this conv's down / up form at this place (large-side map Hl x Wl)?  fp8: its e4m3 form

@@ -157,25 +157,7 @@ int launch_patch_conv(int dt, int out_dt, const PatchArgs& a, int gx, hipStream_
   return launch_patch_conv_bf16(a, gx, s);
 }
 
-// ---------------------------------------------------------------- deep_conv host side
-int launch_deep_conv_f32(const DeepArgs& a, int gx, hipStream_t s);
-int launch_deep_conv_bf16(const DeepArgs& a, int gx, hipStream_t s);
-int launch_deep_conv_bf16_f32(const DeepArgs& a, int gx, hipStream_t s);
-
-size_t deep_conv_lds_bytes(const DeepArgs& a, int dt) {
-  const size_t es = dtype_size(dt);
-  const int CT = a.ct16 * 16;
-  const int TPX = (8 / (a.ct16 / 4)) * a.npt * 16;
-  const size_t pitch = (size_t)a.Cin * (a.fp8 ? 1 : es) + 16;
-  return (size_t)(a.ipt * a.Hi * a.Wi + 1) * pitch + (size_t)2 * CT * (a.fp8 ? 5 : 9) * 16 + (size_t)a.ntaps_all * TPX * 2 + 1024 * 4;
-}
-
-int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s) {
-  if (dt == DT_F32) return launch_deep_conv_f32(a, gx, s);
-  if (out_dt == DT_F32) return launch_deep_conv_bf16_f32(a, gx, s);
-  return launch_deep_conv_bf16(a, gx, s);
-}
-
+// ---------------------------------------------------------------- deep2_conv host side
 int launch_deep2_conv_f32(const DeepArgs& a, int gx, hipStream_t s);
 int launch_deep2_conv_bf16(const DeepArgs& a, int gx, hipStream_t s);
 int launch_deep2_conv_bf16_f32(const DeepArgs& a, int gx, hipStream_t s);

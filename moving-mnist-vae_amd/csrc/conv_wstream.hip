@@ -453,7 +453,7 @@ static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
 }
 
 static bool wstream_enabled() {
-  static const int enabled = [] { const char* e = getenv("MMVAE_WSTREAM"); return e ? atoi(e) : 1; }();
+  constexpr int enabled = 1;
   return enabled != 0;
 }
 // The geometries with an instantiation (kind):
@@ -563,7 +563,7 @@ int try_wgrad_stream_pair(int dt, const WgradArgs& a, const void* P2, float* dW2
 //   packed [Ca][16] matrix; bn_part (optional, needs the prologue, Ca = 16 and no x2): [blocks][2][16] BatchNorm-backward sums of P's BatchNorm.
 //   Returns the number of blocks (> 0) when taken, 0 when the shape is not this kernel's, <0 on error.
 bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a) {
-  static const int enabled = [] { const char* e = getenv("MMVAE_WSTREAM_DG"); return e ? atoi(e) : 1; }();
+  constexpr int enabled = 1;
   const int kind = wstream_kind(dt, a);
   return enabled != 0 && (kind == 1 || kind == 2) && !a.proG_scale;
 }

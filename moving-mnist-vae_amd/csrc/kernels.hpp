@@ -157,7 +157,7 @@ size_t patch_conv_lds_bytes(const PatchArgs& a, int dt);
 void patch_conv_x2_carve(PatchArgs& a, int dt);
 int patch_conv_slots(const PatchArgs& a, int dt);
 int launch_patch_conv(int dt, int out_dt, const PatchArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
-// ---- deep-layer implicit GEMM (conv_deep.inc): resident unpadded patch + streamed weights, 512 threads
+// ---- deep-layer implicit GEMM (conv_deep2.inc): resident unpadded patch, weights from L2 straight into MFMA fragments
 struct DeepPhase { int ph, pw, Hq, Wq, ntaps, tap0; long w_off; };
 struct DeepArgs {
   const void* x; const void* w; void* y;
@@ -173,8 +173,6 @@ struct DeepArgs {
   long long* ts;               // developer builds only (MMVAE_DEEP2_TS): per-block cycle stamps
   int wfrag;                   // weights are fragment-major (PackArgs::frag)
 };
-size_t deep_conv_lds_bytes(const DeepArgs& a, int dt);
-int launch_deep_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);   // returns stats rows (= gx) or <0
 size_t deep2_conv_lds_bytes(const DeepArgs& a, int dt);
 int launch_deep2_conv(int dt, int out_dt, const DeepArgs& a, int gx, hipStream_t s);  // conv_deep2.inc; returns stats rows (= gx) or <0
 // ---- position-major implicit GEMM for q-grids up to 4x4 (conv_pos.inc; bf16, fragment-major weights): an MFMA column is an image, so

@@ -149,7 +149,7 @@ Net::Net(const NetCfg& c) : cfg(c) {
   // (the same mechanism as an fp8 layer's weight scale).
   if (cfg.fp8 && !dec.empty()) {
     Block& L = dec.back();
-    static const bool env = [] { const char* e = getenv("MMVAE_FP8_STORE"); return !(e && e[0] == '0'); }();
+    constexpr bool env = true;
     if (env && !L.identity && L.C == 16 && L.Cin == 16 && L.Hin == 32 && Sd == 64 && c.out_ch == 1 && convT4_stream_ok(DT_BF16, 16, 16, 4, 2, 1, 32, 32) &&
         tail_fwd_stream_ok(DT_BF16, 1, 64, 64) && join_bwd_stream_ok(DT_BF16, 1, 16, 32, 64)) {
       store8 = true;
@@ -275,8 +275,7 @@ int Net::run_up(const ConvW& w, char* base, int N, const void* S, int Hs, int Ws
 }
 hipStream_t Net::wgrad_stream(hipStream_t s) {
   if (side_state_ == 0) {
-    const char* e = getenv("MMVAE_SIDE_STREAM");
-    side_state_ = (e && e[0] == '0') ? -1 : 1;
+    side_state_ = 1;
     if (side_state_ == 1) {
       bool ok = hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) == hipSuccess;
       for (int i = 0; i < kForkEvents && ok; ++i) ok = hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming) == hipSuccess;
@@ -306,12 +305,12 @@ int Net::side_join(hipStream_t s) {
 // measured: im2col + 1x1 weight gradient 0.39 ms, planar-G patch-tile path 0.42 ms (MMVAE_STEM_PLANAR=1)
 // MMVAE_STEM_FUSED=0 restores reduce -> apply -> im2col -> wgrad
 bool Net::stem_bwd_fused() const {
-  static const bool env = [] { const char* e = getenv("MMVAE_STEM_FUSED"); return !(e && e[0] == '0'); }();
+  constexpr bool env = true;
   return env && cfg.in_ch == 1 && stem_bwd_fusable(cfg.S);
 }
 
 static bool stem_im2col_path() {
-  static const bool v = [] { const char* e = getenv("MMVAE_STEM_PLANAR"); return !(e && e[0] == '1'); }();
+  constexpr bool v = true;
   return v;
 }
 
@@ -337,22 +336,22 @@ int Net::run_wgrad(const ConvW& w, int N, const void* P, int Hs, int Ws, const f
 
 // conv1 (3x3 s2) + 1x1 s2 shortcut weight gradients in one stream pass: encoder.layer1's shape (bf16, 32 -> 32 channels, 32x32 -> 16x16)
 static bool wgrad_pair_ok(int dt, const ConvGeom& g, const ConvGeom& gs, int Hout, int Hin) {
-  static const bool env = [] { const char* e = getenv("MMVAE_WGRAD_PAIR"); return !(e && e[0] == '0'); }();
+  constexpr bool env = true;
   return env && dt == DT_BF16 && g.k == 3 && g.s == 2 && g.p == 1 && gs.k == 1 && gs.s == 2 && gs.p == 0 && g.D0 == 32 && g.D1 == 32 && gs.D0 == 32 &&
          gs.D1 == 32 && Hout == 16 && Hin == 32;
 }
 
 // encoder.layer1.conv2's data gradient + bn1's backward sums in one stream pass (bf16, 32 -> 32 channels, 16x16 maps, one block per stage)
 bool Net::l1_dgrad_stream() const {
-  static const bool env = [] { const char* e = getenv("MMVAE_L1_DGRAD_STREAM"); return !(e && e[0] == '0'); }();
+  constexpr bool env = true;
   if (!env || enc.empty()) return false;
   const Block& B = enc[0];
   return !B.identity && !B.c2.fp8 && conv3_stream_ok(dt(), B.C, B.C, B.c2.k, B.c2.s, B.c2.p, B.Hout, B.Wout);
 }
 
 bool Net::tail_fwd_fused() const {
-  static const bool env = [] { const char* e = getenv("MMVAE_TAIL_FWD_FUSED"); return !(e && e[0] == '0'); }();
-  static const bool bwd_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
+  constexpr bool env = true;
+  constexpr bool bwd_env = true;
   // N does not enter the geometry checks beyond the tile count limit, which the plan's maximum batch already satisfies
   return env && bwd_env && !dec.empty() && dec.back().C == 16 && tail_fwd_fusable(dt(), cfg.out_ch, 1, Sd, Sd) &&
          tail_join_fusable(dt(), cfg.out_ch, 1, Sd, Sd);
@@ -593,7 +592,7 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
     Block& B = enc[i];
     const double cnt = (double)N * B.Hout * B.Wout;
     // shortcut branch (conv + its BatchNorm) on the side stream, concurrently with conv1 -> bn1 -> conv2 -> bn2
-    static const bool side_fwd = [] { const char* e = getenv("MMVAE_SIDE_FWD"); return !(e && e[0] == '0'); }();
+    constexpr bool side_fwd = true;
     // encoder.layer1 (32 -> 32 channels, bf16): conv1 AND the 1x1 shortcut from ONE read of the block input, conv2 likewise a per-wave
     // stream (conv_fstream.hip); both BatchNorms finalise on the caller's stream
     const bool stream1 = !B.identity && !B.c1.fp8 && !B.cs.fp8 && B.cs.k == 1 && B.cs.s == 2 &&
@@ -867,7 +866,7 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     Block& B = dec[i];
     const double cnt = (double)N * B.Hout * B.Wout;
     // upsample (shortcut) branch on the side stream, concurrently with conv1 -> bn1 -> conv2 -> bn2
-    static const bool side_fwd = [] { const char* e = getenv("MMVAE_SIDE_FWD"); return !(e && e[0] == '0'); }();
+    constexpr bool side_fwd = true;
     const bool fork = side_fwd && !B.identity;
     if (!B.identity) {
       if (fork) MM_TRY(side_fork(s));
@@ -968,7 +967,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
                                    bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
   else
     MM_TRY(launch_bn_bwd_apply_nchw(d_recon, r_raw, bnf(bn_out, base, 4), bnf(bn_out, base, 5), bnf(bn_out, base, 6), d_raw, N, cfg.out_ch, HW, s));
-  static const bool tail_fused_env = [] { const char* e = getenv("MMVAE_TAIL_FUSED"); return !(e && e[0] == '0'); }();
+  constexpr bool tail_fused_env = true;
   const bool tail_fused = tail_fused_env && !dec.empty() && dec.back().C == 16 && tail_join_fusable(dt(), cfg.out_ch, N, Sd, Sd);
   // forward did not store the joined activation: the weight gradient recomputes it inside the join-backward reduce pass (below)
   const bool tail_wg_in_reduce = tail_fwd_fused() && tail_fused;

@@ -227,3 +227,63 @@ def test_sync_bn_two_ranks_match_one_process():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ---------------------------------------------------------------------------------------------- CPU: control flow of the rccl path
+def test_gradsync_communicator_path_orders_streams_without_a_peer(monkeypatch):
+    """GradSync(comm=<Communicator>) issues the decoder bucket from a communication stream that (1) waits for the caller's stream, (2) is
+    ordered behind the library's side stream through mmvae_net_join, and only then (3) launches the collective; the encoder bucket follows on
+    the same stream and finish() makes the caller's stream wait for it before Adam reads the sum.  No GPU, no peer: streams, the library
+    and the communicator are recording fakes -- what is tested is the ORDER of the calls, which no single-GPU run can exercise with a peer."""
+    M = importlib.import_module("moving-mnist-vae_amd.model")
+    log = []
+
+    class FakeStream:
+        def __init__(self, name="comm", device=None):
+            self.name, self.cuda_stream = name, 0xC0FFEE if name == "comm" else 0x1
+        def wait_stream(self, other):
+            log.append(("wait_stream", self.name, other.name))
+
+    caller = FakeStream("caller")
+    active = [caller]
+
+    class StreamCtx:
+        def __init__(self, st): self.st = st
+        def __enter__(self): active.append(self.st); log.append(("enter", self.st.name))
+        def __exit__(self, *a): active.pop(); log.append(("exit", self.st.name))
+
+    class FakeLib:
+        def mmvae_net_join(self, h, stream):
+            log.append(("net_join", h, stream, active[-1].name))
+            return 0
+
+    class FakeComm:
+        def all_reduce_(self, t, stream=None):
+            log.append(("all_reduce", int(t.numel()), active[-1].name))
+            t.mul_(2.0)                                     # "sum over two identical ranks"
+
+    monkeypatch.setattr(M.torch.cuda, "Stream", lambda device=None: FakeStream("comm"))
+    monkeypatch.setattr(M.torch.cuda, "current_stream", lambda device=None: caller)
+    monkeypatch.setattr(M.torch.cuda, "stream", lambda st: StreamCtx(st))
+    monkeypatch.setattr(M, "lib", lambda: FakeLib())
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    n, dec_off = 1000, 600
+    fake = types.SimpleNamespace(_flat=torch.zeros(n), _bnf=torch.zeros(7), _sync=None, _dec_off=dec_off, _n_params=n, _h=0xAB,
+                                 _ensure_flat=lambda: None)
+    sync = M.GradSync(fake, broadcast=False, comm=FakeComm())
+    G = torch.ones(n)
+    sync.bucket_ready(G, dec_off, n, side_of=fake)           # what _DecoderFn.backward does with a deferred join
+    sync.bucket_ready(G, 0, dec_off)                         # _EncoderFn.backward
+    scale = sync.finish(G)
+    assert scale == 0.5 and torch.all(G == 2.0)
+    assert log == [
+        ("wait_stream", "comm", "caller"), ("enter", "comm"), ("net_join", 0xAB, 0xC0FFEE, "comm"), ("all_reduce", n - dec_off, "comm"), ("exit", "comm"),
+        ("wait_stream", "comm", "caller"), ("enter", "comm"), ("all_reduce", dec_off, "comm"), ("exit", "comm"),
+        ("wait_stream", "caller", "comm"),
+    ], log
+    # a bucket nobody announced is reduced by finish() itself, after the wait
+    log.clear()
+    G2 = torch.ones(n)
+    sync.bucket_ready(G2, dec_off, n, side_of=fake)
+    sync.finish(G2)
+    assert [e[0] for e in log] == ["wait_stream", "enter", "net_join", "all_reduce", "exit", "wait_stream", "all_reduce"] and torch.all(G2 == 2.0), log
