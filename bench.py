@@ -460,7 +460,32 @@ def main():
         d5, l5 = sub_record("fp8", 1, a.z, a.clips, 10)
         out["config5_fp8"] = {"ms_per_step": 1e3 * d5, "frames_per_sec": frames / d5, "steps": 10, "final_loss": l5,
                               "vs_bf16_same_run": (1e3 * dt / a.steps) / (1e3 * d5),
-                              "note": "BASELINE configs[4]: compute_dtype=fp8 (e4m3 MFMA in the forward convs of the >= 64-channel layers, bf16 storage)"}
+                              "note": "BASELINE configs[4]: compute_dtype=fp8 (e4m3 MFMA in the forward convs of the >= 64-channel layers; e4m3 STORAGE of the last up-block's two branch outputs, bf16 elsewhere)"}
+        # PixelVAE: `categorical_pixelvae_1_kl_0_mmd` through select_model, the same 5120 frames -- a correctness path
+        # (masked 7x7 convs on the generic kernels), recorded so that its cost is a number and not an adjective
+        try:
+            pargs = types.SimpleNamespace(model="categorical_pixelvae_1_kl_0_mmd", input_channels=1, input_image_size=64, intermediate_channels=16,
+                                          z_dimension=a.z, sigma_decoder=0.0, require_rsample=True, num_pixelcnn_layers=3, pixelcnn_activation="ReLu",
+                                          nll=1, quantization="2", decoder_out_channels=2, data_ratio_of_labels=torch.ones(2, device=device),
+                                          dataset="MovingMNIST", quiet=True)
+            torch.manual_seed(0)
+            mp_, _ = pkg.select_model(pargs)
+            mp_ = mp_.to(device).train()
+            op_ = M.FusedAdam(list(mp_.parameters()))
+            bp_ = synthetic_clips(a.clips, 4321, device)
+            pkg.train(mp_, [bp_] * 2, op_, device, pargs, data_mean=DATA_MEAN, data_std=DATA_STD)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            lp = pkg.train(mp_, [bp_] * 3, op_, device, pargs, data_mean=DATA_MEAN, data_std=DATA_STD)[0]
+            torch.cuda.synchronize()
+            d6 = (time.perf_counter() - t3) / 3
+            out["pixelvae"] = {"model": "categorical_pixelvae_1_kl_0_mmd (3 PixelCNN layers, 16 intermediate channels, q = 2)", "frames": frames, "steps": 3,
+                               "ms_per_step": 1e3 * d6, "frames_per_sec": frames / d6, "final_loss": lp[-1],
+                               "vs_vae_same_run": (1e3 * d6) / (1e3 * dt / a.steps)}
+            del mp_, op_, bp_
+            torch.cuda.empty_cache()
+        except Exception as ex:  # noqa: BLE001 -- a sub-record must never take the headline down
+            out["pixelvae"] = {"error": repr(ex)[:300]}
     if rank == 0:
         if not a.no_roofline and a.config == "c2":
             out["roofline"] = dominant_kernel_roofline(M, device, frames)
