@@ -242,6 +242,9 @@ int stem_bwd_part_floats();
 int launch_stem_gram(int dt, const void* x, float* scratch, long scratch_cap_floats, double* R, int N, int S, int Ho, int Wo, hipStream_t s);
 int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const float* ms, const float* mb, float* partials,
                     long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s);   // returns rows
+bool stem_bwd_dg_ok(int dt, int S);
+int launch_stem_bwd_dg(const void* dy1, const void* dys, const void* wd1, const void* wds, const void* y0, const void* x, const float* ms, const float* mb,
+                       float* partials, long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s);   // returns rows
 int launch_stem_bwd_finalize(const float* partials, int nparts, const double* R, const float* w, const float* global_sums, double count,
                              const float* gamma, const float* mean, const float* istd, float* dgamma, float* dbeta, float* dW, hipStream_t s);
 

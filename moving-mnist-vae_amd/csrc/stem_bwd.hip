@@ -29,6 +29,9 @@ namespace mmvae {
 constexpr int kStemPartFloats = 64 + 32 * 32;      // per-block partial: S0[32] S1[32] | image [32][32]
 
 struct StemBwdArgs {
+  // DG (round 4): g is not read -- it is recomputed slab by slab as the data gradient of encoder.layer1's conv1 (3x3 s2 p1, 32 -> 32) plus its
+  // 1x1 s2 shortcut from their dy tensors (dy1, dys: [N][Ho/2][Wo/2][32]) and the packed transposed-form weights (op_pack_up order)
+  const void* dy1; const void* dys; const void* wd1; const void* wds;
   const void* g; const void* y0; const void* x;
   const float* ms; const float* mb;
   float* partials;
@@ -38,8 +41,9 @@ struct StemBwdArgs {
 // Every WAVE streams its own 32-pixel slabs (rps whole output rows of one image) through wave-private LDS: no block barrier in
 // the loop, 16 independent software pipelines per CU.  Lane roles: staging = 16-byte vector `lane + 64k` of the slab (contiguous
 // in memory), fragments = the usual 16x16x32 / 16x16x4 maps over the slab's 32 pixels.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void stem_bwd_kernel(StemBwdArgs a) {
+template <typename T, int MODE, bool DG = false>
+__global__ __launch_bounds__(256, DG ? 3 : sizeof(T) == 2 ? 4 : 2) void stem_bwd_kernel(StemBwdArgs a) {
+  static_assert(!DG || (MODE == 0 && sizeof(T) == 2), "fused layer1 data gradient: bf16 grad mode");
   constexpr int VE = Elem<T>::kVec, ES = sizeof(T);
   constexpr int CV = 32 / VE;                      // 16-byte vectors per pixel of g / y0 / the P slab
   constexpr int NS = MODE == 0 ? 32 * CV / 64 : 1; // g / y0 vectors per lane and slab
@@ -48,14 +52,37 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void stem_bwd_kernel(S
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
   float* sC = reinterpret_cast<float*>(smem);                          // [2][32] mask coefficients (block-shared, read-only)
-  const int wave_bytes = 32 * PITCH + a.prow * a.pw * 4;
+  constexpr int kDyPitch = 96;                                         // bytes per staged dy pixel: 64 + 32 (conflict-free ds_read_b128 of 16 pixels)
+  constexpr int kDyRow = 17 * kDyPitch;                                // 16 pixels + one zero pixel on the right
+  const int wave_bytes = 32 * PITCH + a.prow * a.pw * 4 + (DG ? 2 * kDyRow : 0);
   char* sP = smem + 256 + wv * wave_bytes;                             // this wave's P slab [32][32] T
   float* sX = reinterpret_cast<float*>(sP + 32 * PITCH);               // this wave's image patch [prow][pw] f32, 4 halo columns a side
+  char* sDy = reinterpret_cast<char*>(sX) + a.prow * a.pw * 4;         // DG: two dy rows [17][96 B]
+  char* sWf = smem + 256 + 4 * wave_bytes;                             // DG: 20 A fragments of 1 KB: [9 conv1 taps + shortcut][2 ci halves][lane]
   const T* __restrict__ G = reinterpret_cast<const T*>(a.g);
   const T* __restrict__ Y = reinterpret_cast<const T*>(a.y0);
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   if (MODE == 0 && t < 64) sC[t] = t < 32 ? a.ms[t] : a.mb[t - 32];
   for (int i = lane; i < a.prow * a.pw; i += 64) sX[i] = 0.f;          // the halo columns stay zero
+  if constexpr (DG) {
+    // A fragment (tap slot f, ci half m): lane (gq, r) = row ci 16 m + r, k = co 8 gq ..: out of op_pack_up's row-major [ci][tap][co] matrices of
+    // the four stride phases (taps per phase 1, 2, 2, 4; element offsets 0, 1024, 3072, 5120)
+    for (int i = t; i < 20 * 64; i += 256) {
+      const int fm = i >> 6, l = i & 63, f = fm >> 1, m = fm & 1, rr = l & 15, g4 = l >> 4;
+      const T* src;
+      if (f < 9) {
+        const int pbase = f < 1 ? 0 : f < 3 ? 1024 : f < 5 ? 3072 : 5120, ntp = f < 1 ? 1 : f < 5 ? 2 : 4, tp = f < 1 ? 0 : f < 3 ? f - 1 : f < 5 ? f - 3 : f - 5;
+        src = reinterpret_cast<const T*>(a.wd1) + pbase + ((16 * m + rr) * ntp + tp) * 32 + 8 * g4;
+      } else {
+        src = reinterpret_cast<const T*>(a.wds) + (16 * m + rr) * 32 + 8 * g4;
+      }
+      *reinterpret_cast<Vec16*>(sWf + i * 16) = *reinterpret_cast<const Vec16*>(src);
+    }
+    if (lane < 12) {                                                   // the zero pixel (16) of both rows
+      const int row = lane / 6, v = lane % 6;
+      *reinterpret_cast<Vec16*>(sDy + row * kDyRow + 16 * kDyPitch + v * 16) = Vec16{{0, 0, 0, 0}};
+    }
+  }
   __syncthreads();
   const int cv = lane % CV;
   float s1[VE];                                     // sum gm * y0 (sum gm comes out of the MFMA: ones column of B)
@@ -90,11 +117,25 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void stem_bwd_kernel(S
 
   // ---- software pipeline of this wave: registers of the NEXT slab
   Vec16 gv[NS], yv[NS], xv[NXV];
-  int r0_c = 0;
+  Vec16 dv[2];                                      // DG: the two dy rows of the next slab (16 pixels x 32 channels = one vector per lane)
+  int r0_c = 0, ph_n = 0;
   auto issue = [&](int slab) {
     const int n = slab / a.slabs_per_img, h0 = (slab - n * a.slabs_per_img) * a.rps;
     r0_c = 2 * h0 - 2;
-    if constexpr (MODE == 0) {
+    if constexpr (DG) {
+      // output row h0 of the 32 x 32 grid: phase ph = h0 & 1, q-row hq = h0 >> 1.  ph = 0: taps kh = 1 (dy1 row hq) + the shortcut (dys row hq);
+      // ph = 1: kh = 2 (dy1 row hq) and kh = 0 (dy1 row hq + 1, zero below the map)
+      const int hq = h0 >> 1, Hs = a.Ho >> 1;
+      ph_n = h0 & 1;
+      const long rb = ((long)n * Hs + hq) * (long)(a.Wo >> 1) * 32 + lane * VE;
+      dv[0] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(a.dy1) + rb);
+      dv[1] = Vec16{{0, 0, 0, 0}};
+      if (!ph_n) dv[1] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(a.dys) + rb);
+      else if (hq + 1 < Hs) dv[1] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(a.dy1) + rb + (long)(a.Wo >> 1) * 32);
+      const long base = (((long)n * a.Ho + h0) * a.Wo) * 32 + lane * VE;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) yv[k] = *reinterpret_cast<const Vec16*>(Y + base + k * 64 * VE);
+    } else if constexpr (MODE == 0) {
       const long base = (((long)n * a.Ho + h0) * a.Wo) * 32 + lane * VE;
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
@@ -109,7 +150,46 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void stem_bwd_kernel(S
       if ((unsigned)(r0_c + xrow[k]) < (unsigned)a.H) xv[k] = *reinterpret_cast<const Vec16*>(X + (xbase + (long)xrow[k] * a.W + xcol[k]));
     }
   };
+  int ph_c = 0;                                     // DG: phase of the slab being committed
   auto commit = [&]() {
+    if constexpr (DG) {
+      // ---- g slab = data gradient of conv1 (+ shortcut) for this output row, on the matrix cores: D[ci][pixel wq of column phase pw]
+      *reinterpret_cast<Vec16*>(sDy + (lane >> 2) * kDyPitch + (lane & 3) * 16) = dv[0];
+      *reinterpret_cast<Vec16*>(sDy + kDyRow + (lane >> 2) * kDyPitch + (lane & 3) * 16) = dv[1];
+      const char* b0 = sDy + r * kDyPitch + gq * 16;               // B fragment: pixel r (+ dw), channels (co) 8 gq ..
+      const Vec16 r0d0 = *reinterpret_cast<const Vec16*>(b0), r0d1 = *reinterpret_cast<const Vec16*>(b0 + kDyPitch);
+      const Vec16 r1d0 = *reinterpret_cast<const Vec16*>(b0 + kDyRow), r1d1 = *reinterpret_cast<const Vec16*>(b0 + kDyRow + kDyPitch);
+      auto wf = [&](int f, int m) { return *reinterpret_cast<const Vec16*>(sWf + ((f * 2 + m) * 64 + lane) * 16); };
+      f32x4 d[2][2];                                               // [pw][ci half]
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        d[0][m] = (f32x4){0, 0, 0, 0}; d[1][m] = (f32x4){0, 0, 0, 0};
+        if (ph_c == 0) {
+          // phase (0,0): tap (1,1) dw 0 [slot 0] + shortcut [slot 9] on dys (row buffer 1);  phase (0,1): taps (1,0) dw 1 [1], (1,2) dw 0 [2]
+          d[0][m] = mma_bf16(wf(0, m), r0d0, d[0][m]);
+          d[0][m] = mma_bf16(wf(9, m), r1d0, d[0][m]);
+          d[1][m] = mma_bf16(wf(1, m), r0d1, d[1][m]);
+          d[1][m] = mma_bf16(wf(2, m), r0d0, d[1][m]);
+        } else {
+          // phase (1,0): taps (0,1) dh 1 [3], (2,1) dh 0 [4];  phase (1,1): (0,0) dh 1 dw 1 [5], (0,2) dh 1 dw 0 [6], (2,0) dh 0 dw 1 [7], (2,2) [8]
+          d[0][m] = mma_bf16(wf(3, m), r1d0, d[0][m]);
+          d[0][m] = mma_bf16(wf(4, m), r0d0, d[0][m]);
+          d[1][m] = mma_bf16(wf(5, m), r1d1, d[1][m]);
+          d[1][m] = mma_bf16(wf(6, m), r1d0, d[1][m]);
+          d[1][m] = mma_bf16(wf(7, m), r0d1, d[1][m]);
+          d[1][m] = mma_bf16(wf(8, m), r0d0, d[1][m]);
+        }
+      }
+      // lane (gq, r): channels 16 m + 4 gq .. + 3 of pixel 2 r + pw -> the slab [pixel][32 channels] as bf16 (what the stored gradient was)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          *reinterpret_cast<uint2*>(sP + (2 * r + pw) * PITCH + (16 * m + 4 * gq) * 2) =
+              make_uint2(pack2_bf16(d[pw][m][0], d[pw][m][1]), pack2_bf16(d[pw][m][2], d[pw][m][3]));
+#pragma unroll
+      for (int k = 0; k < NS; ++k) gv[k] = *reinterpret_cast<const Vec16*>(sP + (lane + 64 * k) * 16);
+    }
     if constexpr (MODE == 0) {
       float ms[VE], mb[VE];
 #pragma unroll
@@ -148,6 +228,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 4 : 2) void stem_bwd_kernel(S
   int slab = gw;
   if (slab < a.nslabs) issue(slab);
   for (; slab < a.nslabs; slab += gstride) {
+    ph_c = ph_n;
     commit();
     if constexpr (MODE == 1) {
       // im2col slab of the image itself: taps 16bh .. 16bh+15 of pixel bq (tap 25 = 1, taps > 25 = 0)
@@ -472,6 +553,26 @@ int launch_stem_bwd(int dt, const void* g, const void* y0, const void* x, const 
   else hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 0>), dim3(gx), dim3(256), stem_lds(a, dt), s, a);
   note_launch_bytes((double)N * ((double)S * S * 2.0 + 2.0 * Ho * Wo * 32 * 2.0));     // x, g, y0
   const int rc = check_launch("stem_bwd");
+  return rc ? rc : gx;
+}
+
+// The same pass with the incoming gradient recomputed from encoder.layer1's dy tensors (see StemBwdArgs): bf16, S = 64 (one output row per slab)
+bool stem_bwd_dg_ok(int dt, int S) { return dt == DT_BF16 && S == 64; }
+int launch_stem_bwd_dg(const void* dy1, const void* dys, const void* wd1, const void* wds, const void* y0, const void* x, const float* ms, const float* mb,
+                       float* partials, long partials_cap_floats, int N, int S, int Ho, int Wo, hipStream_t s) {
+  StemBwdArgs a; memset(&a, 0, sizeof(a));
+  const int rc0 = stem_geom(a, DT_BF16, N, S, Ho, Wo);
+  if (rc0 < 0) return rc0;
+  if (a.rps != 1 || Wo != 32) { set_error("stem_bwd_dg: needs 32-pixel output rows"); return MMVAE_ERR_UNSUPPORTED; }
+  a.dy1 = dy1; a.dys = dys; a.wd1 = wd1; a.wds = wds; a.y0 = y0; a.x = x; a.ms = ms; a.mb = mb; a.partials = partials;
+  int gx = 768;                                          // three 256-thread blocks per CU (47 KB of LDS each): one resident round
+  if (gx * 4 > a.nslabs) gx = (a.nslabs + 3) / 4;
+  if ((long)gx * kStemPartFloats > partials_cap_floats) gx = (int)(partials_cap_floats / kStemPartFloats);
+  if (gx < 1) { set_error("stem_bwd: partials buffer too small"); return MMVAE_ERR_WORKSPACE; }
+  const size_t lds = 256 + 4 * ((size_t)32 * 32 * 2 + (size_t)a.prow * a.pw * 4 + 2 * 17 * 96) + 20 * 1024;
+  hipLaunchKernelGGL((stem_bwd_kernel<bf16_t, 0, true>), dim3(gx), dim3(256), lds > (size_t)kStemPartFloats * 4 ? lds : (size_t)kStemPartFloats * 4, s, a);
+  note_launch_bytes((double)N * ((double)S * S * 2.0 + Ho * Wo * 32 * 2.0 + 2.0 * (Ho / 2) * (Wo / 2) * 32 * 2.0));     // x, y0, dy1, dys
+  const int rc = check_launch("stem_bwd_dg");
   return rc ? rc : gx;
 }
 

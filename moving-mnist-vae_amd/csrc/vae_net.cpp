@@ -349,6 +349,16 @@ bool Net::l1_dgrad_stream() const {
   return !B.identity && !B.c2.fp8 && conv3_stream_ok(dt(), B.C, B.C, B.c2.k, B.c2.s, B.c2.p, B.Hout, B.Wout);
 }
 
+// The stem's backward recomputes its incoming gradient (encoder.layer1's conv1 3x3 s2 + 1x1 s2 shortcut data gradients) instead of reading it:
+// bf16, 64x64 images, the reference's first stage (32 -> 32 channels, strided block with a 1x1 shortcut), row-major packed weights.  MMVAE_STEM_DG=0: off
+bool Net::stem_dg_fused() const {
+  static const bool env = [] { const char* e = getenv("MMVAE_STEM_DG"); return !(e && e[0] == '0'); }();
+  if (!env || enc.empty() || !stem_bwd_fused() || !stem_bwd_dg_ok(dt(), cfg.S)) return false;
+  const Block& B = enc[0];
+  return !B.identity && B.Cin == 32 && B.C == 32 && B.c1.k == 3 && B.c1.s == 2 && B.c1.p == 1 && B.cs.k == 1 && B.cs.s == 2 && B.cs.p == 0 &&
+         !B.c1.fp8 && !B.cs.fp8 && B.c1.wscale == 1.f && B.cs.wscale == 1.f && frag_up(B.c1) == 0 && frag_up(B.cs) == 0 && H1 == 32 && B.Hout == 16;
+}
+
 bool Net::tail_fwd_fused() const {
   constexpr bool env = true;
   constexpr bool bwd_env = true;
@@ -768,7 +778,10 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     if (!taken) MM_TRY(run_wgrad(B.c1, N, base + dy1o, B.Hout, B.Wout, nullptr, nullptr, xin, B.Hin, B.Win, xs, xb, grads, wsm));
     if (late.nparts > 0) MM_TRY(launch_wgrad_reduce(late, wsm));
     MM_TRY(side_mark(i));
-    if (B.identity)     // d_xin already holds the shortcut's share: the main path's data gradient is added to it
+    if (i == 0 && stem_dg_fused()) {
+      // the gradient of the stem's output is never a tensor: stem_bwd_kernel<DG> recomputes it row by row from dy1 / dys (below)
+      stem_dy1_ = dy1o; stem_dys_ = dyso;
+    } else if (B.identity)     // d_xin already holds the shortcut's share: the main path's data gradient is added to it
       MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     else                // one kernel: the 1x1 stride-2 shortcut's data gradient is a second source of the 3x3 conv's (phase (0,0))
       MM_TRY(run_up(B.c1, base, N, base + dy1o, B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, s, &B.cs,
@@ -780,8 +793,12 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     // one pass over g and y0 (stem_bwd.hip): BatchNorm sums and the three pixel reductions dW is an affine function of; no dy
     // tensor, no im2col, nothing waits on a grid-wide reduction except the 32-block finalize
     const long npix = (long)N * H1 * W1;
-    const int np = launch_stem_bwd(dt(), base + P.g[cur], base + P.y0, base + P.x_t, bnf(bn0, base, 2), bnf(bn0, base, 3), part, kPartialFloats,
-                                   N, cfg.S, H1, W1, s);
+    const Block& B0 = enc[0];
+    const int np = stem_dg_fused()
+        ? launch_stem_bwd_dg(base + stem_dy1_, base + stem_dys_, base + P.packed + B0.c1.packU * (long)esz(), base + P.packed + B0.cs.packU * (long)esz(),
+                             base + P.y0, base + P.x_t, bnf(bn0, base, 2), bnf(bn0, base, 3), part, kPartialFloats, N, cfg.S, H1, W1, s)
+        : launch_stem_bwd(dt(), base + P.g[cur], base + P.y0, base + P.x_t, bnf(bn0, base, 2), bnf(bn0, base, 3), part, kPartialFloats,
+                          N, cfg.S, H1, W1, s);
     MM_TRY(np);
     const float* gsum = nullptr; double cnt = (double)npix;
     if (sync_bn_on()) {

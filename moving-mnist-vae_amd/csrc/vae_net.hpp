@@ -142,6 +142,8 @@ class Net {
   // recomputing wgrad and the recomputing join backward.  MMVAE_TAIL_FWD_FUSED=0 restores join -> conv.
   bool tail_fwd_fused() const;
   bool stem_bwd_fused() const;       // stem backward as one pass (stem_bwd.hip)
+  bool stem_dg_fused() const;        // ... with encoder.layer1's data gradient recomputed inside it (no stored gradient of the stem's output)
+  long stem_dy1_ = 0, stem_dys_ = 0; // workspace offsets of layer1's dy1 / dys of the running backward pass
   // decoder_bwd leaves its weight gradients running on the side stream; encoder_bwd (or join()) orders them before the caller's stream
   bool defer_join_ = false;
   int (*ar_fn_)(float*, long long, void*, void*) = nullptr; void* ar_user_ = nullptr; int ar_world_ = 1;
