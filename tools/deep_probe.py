@@ -8,7 +8,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("moving-mnist-vae_amd._lib")
 
 # name, transposed, Cin, Cout, k, s, p, H (input side of the forward op)
