@@ -817,9 +817,11 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   const int tiles_ab = (a.Ca / TA) * (a.Cb / TB);
   const int zg = (a.ntaps + b.TG - 1) / b.TG;
   const long wsize = (long)a.Ca * a.Cb * a.ntaps;
-  // grid: as many persistent blocks as the CUs can hold (LDS-limited), each flushing one partial image tile
-  int occ = (int)((160 * 1024) / lds); if (occ > 6) occ = 6; if (occ < 1) occ = 1;
-  long gx = (256L * occ) / ((long)tiles_ab * zg); if (gx < 1) gx = 1;
+  // grid: ~176 persistent blocks in all, each flushing one partial image tile.  Measured in round 4 (bench.py, ms per step): one block per
+  // LDS slot (up to 1536 blocks) 6.59, 256 blocks 6.47 / 6.40, 192 6.35 / 6.41, 160 6.39, 128 6.36, 96 6.55, 64 6.96 -- these launches run on
+  // the side stream beside the data-gradient chain: fewer blocks leave CUs to the critical path and write fewer partial images (the reduce
+  // that follows moves as many bytes as the blocks wrote)
+  long gx = 176L / ((long)tiles_ab * zg); if (gx < 1) gx = 1;
   if (!a.scratch) { set_error("wgrad: the partial-image scratch is required (no atomic flush path)"); return MMVAE_ERR_ARG; }
   const bool partial = true;
   if (partial) {

@@ -1,4 +1,5 @@
 // Host side of the patch-tile weight-gradient path + the reduction of the per-block partial images.
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace mmvae {
