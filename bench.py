@@ -181,27 +181,31 @@ def _time_calls(fn, reps, warm=2):
 
 
 # The layers whose weight gradient runs on wgrad2_kernel in the step (the others: uplayer5 inside join_bwd_stream_kernel, uplayer4 and
-# encoder.layer1's 3x3 convs on wgrad_stream_kernel, the stem / tail / heads on their own kernels):
+# encoder.layer1's 3x3 convs on wgrad_stream_kernel, the 2x2 / 4x4-map layers -- encoder.layer4.conv1 / conv2, decoder.uplayer1.conv2 /
+# upsample -- on wgrad_pos_kernel since round 4, the stem / tail / heads on their own kernels):
 # name, transposed, Cin, Cout, k, stride, pad, H (input side of the forward op), BatchNorm+ReLU prologue on x
 WGRAD2_LAYERS = [
     ("encoder.layer2.0.conv1", 0, 32, 64, 3, 2, 1, 16, 0), ("encoder.layer2.0.conv2", 0, 64, 64, 3, 1, 1, 8, 1),
     ("encoder.layer2.0.downsample.0", 0, 32, 64, 1, 2, 0, 16, 0),
     ("encoder.layer3.0.conv1", 0, 64, 128, 3, 2, 1, 8, 0), ("encoder.layer3.0.conv2", 0, 128, 128, 3, 1, 1, 4, 1),
     ("encoder.layer3.0.downsample.0", 0, 64, 128, 1, 2, 0, 8, 0),
-    ("encoder.layer4.0.conv1", 0, 128, 256, 3, 2, 1, 4, 0), ("encoder.layer4.0.conv2", 0, 256, 256, 3, 1, 1, 2, 1),
     ("encoder.layer4.0.downsample.0", 0, 128, 256, 1, 2, 0, 4, 0),
-    ("decoder.uplayer1.0.conv1", 0, 128, 128, 1, 1, 0, 2, 1), ("decoder.uplayer1.0.conv2", 1, 128, 128, 4, 2, 1, 2, 1),
-    ("decoder.uplayer1.0.upsample.0", 1, 128, 128, 4, 2, 1, 2, 1),
+    ("decoder.uplayer1.0.conv1", 0, 128, 128, 1, 1, 0, 2, 1),
     ("decoder.uplayer2.0.conv1", 0, 128, 64, 1, 1, 0, 4, 0), ("decoder.uplayer2.0.conv2", 1, 64, 64, 4, 2, 1, 4, 1),
     ("decoder.uplayer2.0.upsample.0", 1, 128, 64, 4, 2, 1, 4, 0),
     ("decoder.uplayer3.0.conv1", 0, 64, 32, 1, 1, 0, 8, 0), ("decoder.uplayer3.0.conv2", 1, 32, 32, 4, 2, 1, 8, 1),
     ("decoder.uplayer3.0.upsample.0", 1, 64, 32, 4, 2, 1, 8, 0),
 ]
+# ... and the four that moved to wgrad_pos_kernel (reported beside the family: `wgrad_pos_layers_isolated_ms`)
+WGRAD_POS_LAYERS = [
+    ("encoder.layer4.0.conv1", 0, 128, 256, 3, 2, 1, 4, 0), ("encoder.layer4.0.conv2", 0, 256, 256, 3, 1, 1, 2, 1),
+    ("decoder.uplayer1.0.conv2", 1, 128, 128, 4, 2, 1, 2, 1), ("decoder.uplayer1.0.upsample.0", 1, 128, 128, 4, 2, 1, 2, 1),
+]
 
 
 def dominant_kernel_roofline(M, device, N, reps=10):
     """`roofline`: the kernel family with the most GPU time per step in the committed kernel statistics (profiles/*_top_kernels.json) is
-    wgrad2_kernel, the weight gradient of the channel-heavy layers (19 launches, side stream).  Every layer that runs on it is timed
+    wgrad2_kernel, the weight gradient of the channel-heavy layers on 8x8 / 16x16 maps and of the 1x1 convs (15 launches, side stream).  Every layer that runs on it is timed
     in isolation through the C ABI (mmvae_conv2d_wgrad: kernel + partial-image reduce, events on the launch stream), the SLOWEST one is
     the family's largest instance and is reported against the roofline that bounds it: algorithmic bytes = x + dy (bf16) + the weight
     gradient (f32), flops = 2 * pixels * Cin * Cout * k^2; bound = mfma when flops / bytes exceeds the bf16 ridge (2.5 PF / 8 TB/s)."""
@@ -223,6 +227,22 @@ def dominant_kernel_roofline(M, device, N, reps=10):
         ms = _time_calls(fn, 4, warm=1)
         pix = N * (H * H if tr else Ho * Ho)
         rows.append(dict(layer=name, ms=ms, bytes=(x.numel() + dy.numel()) * 2 + dw.numel() * 4, flop=2.0 * pix * Cin * Cout * k * k))
+        del x, dy, dw
+    # the four layers that left the family for wgrad_pos_kernel in round 4, timed the same way (kernel + ordered reduce)
+    pos_rows = {}
+    for name, tr, Cin, Cout, k, sd, p, H, pro in WGRAD_POS_LAYERS:
+        Ho = (H - 1) * sd - 2 * p + k if tr else (H + 2 * p - k) // sd + 1
+        x = torch.randn(N, H, H, Cin, device=device).to(torch.bfloat16)
+        dy = torch.randn(N, Ho, Ho, Cout, device=device).to(torch.bfloat16)
+        dw = torch.zeros((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device=device)
+        sc, sh = torch.rand(Cin, device=device) + 0.5, torch.randn(Cin, device=device) * 0.1
+
+        def fnp():
+            L.check(lib.mmvae_conv2d_wgrad(1, tr, L.ptr(x), L.ptr(dy), L.ptr(dw), N, H, H, Cin, Cout, k, sd, p, L.ptr(sc) if pro else None,
+                                           L.ptr(sh) if pro else None, 1, L.ptr(wsc), st), name)
+        ms = _time_calls(fnp, 4, warm=1)
+        flop = 2.0 * N * (H * H if tr else Ho * Ho) * Cin * Cout * k * k
+        pos_rows[name] = {"ms": round(ms, 4), "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 1), "frac_of_mfma_peak": round(flop / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 3)}
         del x, dy, dw
     worst = max(rows, key=lambda r: r["ms"])
     name = worst["layer"]
@@ -250,7 +270,7 @@ def dominant_kernel_roofline(M, device, N, reps=10):
             "algorithmic_bytes_per_launch": alg, "algorithmic_flop_per_launch": flop, "avg_launch_ms": ms,
             "achieved_GBs": gbs, "achieved_TFLOPs": tfs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "frac_of_mfma_peak": tfs / MFMA_PEAK_TFLOPS,
             "family_in_step": fam, "family_layers_isolated_ms": {r["layer"]: round(r["ms"], 4) for r in rows},
-            "family_isolated_ms_sum": sum(r["ms"] for r in rows)}
+            "family_isolated_ms_sum": sum(r["ms"] for r in rows), "wgrad_pos_layers_isolated": pos_rows}
 
 
 def largest_launch_roofline(M, device, N, reps=10):

@@ -509,10 +509,9 @@ static int try_deep2(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
   return launch_deep2_conv(dt, out_dt, b, gx, s);
 }
 
-// pos_conv_kernel (conv_pos.inc): q-grids up to 4x4, MFMA columns = images, padded (position, tap) pairs not computed.  MMVAE_POS=0: off
+// pos_conv_kernel (conv_pos.inc): q-grids up to 4x4, MFMA columns = images, padded (position, tap) pairs not computed
 static int try_pos(int dt, int out_dt, const GatherArgs& a, hipStream_t s) {
-  static const int enabled = [] { const char* e = getenv("MMVAE_POS"); return e ? atoi(e) : 1; }();
-  if (!enabled || conv_force_v1() || dt != DT_BF16 || out_dt != DT_BF16 || !a.wfrag || a.fp8 || a.gup == 0) return 0;
+  if (conv_force_v1() || dt != DT_BF16 || out_dt != DT_BF16 || !a.wfrag || a.fp8 || a.gup == 0) return 0;
   if (a.x_planar || a.y_planes || a.x2 || a.bias || a.Hi != a.Wi || a.Ho != a.Wo || a.Cout % 32 != 0) return 0;
   const int up = a.gup == 2 ? 1 : 0;
   if (!pos_conv_takes(a.gk, a.gs, a.gp, up, a.Hi, a.Ho, a.Cin)) return 0;

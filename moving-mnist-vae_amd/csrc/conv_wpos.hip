@@ -175,8 +175,7 @@ __global__ __launch_bounds__(NTHR, 1) void wgrad_pos_kernel(WposArgs a) {
 
 // Returns 1 when taken (kernel + ordered reduce launched), 0 when the shape is not this kernel's, < 0 on error.
 int try_wgrad_pos(int dt, const WgradArgs& a, hipStream_t s) {
-  static const int enabled = [] { const char* e = getenv("MMVAE_WPOS"); return e ? atoi(e) : 1; }();
-  if (!enabled || dt != DT_BF16 || a.P_planar || a.G_planar || !a.scratch || (a.proP_scale && a.proG_scale)) return 0;
+  if (dt != DT_BF16 || a.P_planar || a.G_planar || !a.scratch || (a.proP_scale && a.proG_scale)) return 0;
   if (a.Hp != a.Wp || a.Hg != a.Wg || a.Hp < 1 || a.Hp > 4 || a.Hg > 4 || a.Ca % 64 != 0 || a.Cb % 64 != 0) return 0;
   if (a.ksz < 1 || a.ksz > 4 || a.ntaps != a.ksz * a.ksz || a.ksz * a.ksz < 4) return 0;       // one wave per tap: 4, 9 or 16 waves
   if ((a.Ca_valid && a.Ca_valid != a.Ca) || (a.Cb_valid && a.Cb_valid != a.Cb)) return 0;

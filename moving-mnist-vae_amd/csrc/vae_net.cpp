@@ -350,10 +350,9 @@ bool Net::l1_dgrad_stream() const {
 }
 
 // The stem's backward recomputes its incoming gradient (encoder.layer1's conv1 3x3 s2 + 1x1 s2 shortcut data gradients) instead of reading it:
-// bf16, 64x64 images, the reference's first stage (32 -> 32 channels, strided block with a 1x1 shortcut), row-major packed weights.  MMVAE_STEM_DG=0: off
+// bf16, 64x64 images, the reference's first stage (32 -> 32 channels, strided block with a 1x1 shortcut), row-major packed weights
 bool Net::stem_dg_fused() const {
-  static const bool env = [] { const char* e = getenv("MMVAE_STEM_DG"); return !(e && e[0] == '0'); }();
-  if (!env || enc.empty() || !stem_bwd_fused() || !stem_bwd_dg_ok(dt(), cfg.S)) return false;
+  if (enc.empty() || !stem_bwd_fused() || !stem_bwd_dg_ok(dt(), cfg.S)) return false;
   const Block& B = enc[0];
   return !B.identity && B.Cin == 32 && B.C == 32 && B.c1.k == 3 && B.c1.s == 2 && B.c1.p == 1 && B.cs.k == 1 && B.cs.s == 2 && B.cs.p == 0 &&
          !B.c1.fp8 && !B.cs.fp8 && B.c1.wscale == 1.f && B.cs.wscale == 1.f && frag_up(B.c1) == 0 && frag_up(B.cs) == 0 && H1 == 32 && B.Hout == 16;
