@@ -820,7 +820,11 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   // LDS slot (up to 1536 blocks) 6.59, 256 blocks 6.47 / 6.40, 192 6.35 / 6.41, 160 6.39, 128 6.36, 96 6.55, 64 6.96 -- these launches run on
   // the side stream beside the data-gradient chain: fewer blocks leave CUs to the critical path and write fewer partial images (the reduce
   // that follows moves as many bytes as the blocks wrote)
-  long gx = 176L / ((long)tiles_ab * zg); if (gx < 1) gx = 1;
+  // (the channel-heavy layers only -- operands below 200 MB; the big thin layers that still come here -- the deeper variant's identity
+  // blocks at 32x32 / 64x64, the PixelCNN's 7x7 convs -- stream 0.3 .. 1.3 GB and keep one block per LDS slot)
+  const long op_bytes = ((long)a.N * a.Hp * a.Wp * a.Ca + (long)a.N * a.Hg * a.Wg * a.Cb) * (long)dtype_size(dt);
+  int occ = (int)((160 * 1024) / lds); if (occ > 6) occ = 6; if (occ < 1) occ = 1;
+  long gx = (op_bytes < (200L << 20) ? 176L : 256L * occ) / ((long)tiles_ab * zg); if (gx < 1) gx = 1;
   if (!a.scratch) { set_error("wgrad: the partial-image scratch is required (no atomic flush path)"); return MMVAE_ERR_ARG; }
   const bool partial = true;
   if (partial) {
