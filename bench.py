@@ -181,34 +181,34 @@ def _time_calls(fn, reps, warm=2):
 
 
 # The layers whose weight gradient runs on wgrad2_kernel in the step (the others: uplayer5 inside join_bwd_stream_kernel, uplayer4 and
-# encoder.layer1's 3x3 convs on wgrad_stream_kernel, the 2x2 / 4x4-map layers -- encoder.layer4.conv1 / conv2, decoder.uplayer1.conv2 /
-# upsample -- on wgrad_pos_kernel since round 4, the stem / tail / heads on their own kernels):
+# encoder.layer1's 3x3 convs on wgrad_stream_kernel, the layers whose small-side map is at most 4x4 on wgrad_pos_kernel since round 4, the
+# stem / tail / heads on their own kernels):
 # name, transposed, Cin, Cout, k, stride, pad, H (input side of the forward op), BatchNorm+ReLU prologue on x
 WGRAD2_LAYERS = [
     ("encoder.layer2.0.conv1", 0, 32, 64, 3, 2, 1, 16, 0), ("encoder.layer2.0.conv2", 0, 64, 64, 3, 1, 1, 8, 1),
     ("encoder.layer2.0.downsample.0", 0, 32, 64, 1, 2, 0, 16, 0),
-    ("encoder.layer3.0.conv1", 0, 64, 128, 3, 2, 1, 8, 0), ("encoder.layer3.0.conv2", 0, 128, 128, 3, 1, 1, 4, 1),
     ("encoder.layer3.0.downsample.0", 0, 64, 128, 1, 2, 0, 8, 0),
     ("encoder.layer4.0.downsample.0", 0, 128, 256, 1, 2, 0, 4, 0),
     ("decoder.uplayer1.0.conv1", 0, 128, 128, 1, 1, 0, 2, 1),
-    ("decoder.uplayer2.0.conv1", 0, 128, 64, 1, 1, 0, 4, 0), ("decoder.uplayer2.0.conv2", 1, 64, 64, 4, 2, 1, 4, 1),
-    ("decoder.uplayer2.0.upsample.0", 1, 128, 64, 4, 2, 1, 4, 0),
+    ("decoder.uplayer2.0.conv1", 0, 128, 64, 1, 1, 0, 4, 0),
     ("decoder.uplayer3.0.conv1", 0, 64, 32, 1, 1, 0, 8, 0), ("decoder.uplayer3.0.conv2", 1, 32, 32, 4, 2, 1, 8, 1),
     ("decoder.uplayer3.0.upsample.0", 1, 64, 32, 4, 2, 1, 8, 0),
 ]
-# ... and the four that moved to wgrad_pos_kernel (reported beside the family: `wgrad_pos_layers_isolated_ms`)
+# ... and the eight that moved to wgrad_pos_kernel in round 4 (small-side map up to 4x4, large-side up to 8x8; reported beside the family)
 WGRAD_POS_LAYERS = [
+    ("encoder.layer3.0.conv1", 0, 64, 128, 3, 2, 1, 8, 0), ("encoder.layer3.0.conv2", 0, 128, 128, 3, 1, 1, 4, 1),
     ("encoder.layer4.0.conv1", 0, 128, 256, 3, 2, 1, 4, 0), ("encoder.layer4.0.conv2", 0, 256, 256, 3, 1, 1, 2, 1),
     ("decoder.uplayer1.0.conv2", 1, 128, 128, 4, 2, 1, 2, 1), ("decoder.uplayer1.0.upsample.0", 1, 128, 128, 4, 2, 1, 2, 1),
+    ("decoder.uplayer2.0.conv2", 1, 64, 64, 4, 2, 1, 4, 1), ("decoder.uplayer2.0.upsample.0", 1, 128, 64, 4, 2, 1, 4, 0),
 ]
 
 
-def dominant_kernel_roofline(M, device, N, reps=10):
-    """`roofline`: the kernel family with the most GPU time per step in the committed kernel statistics (profiles/*_top_kernels.json) is
-    wgrad2_kernel, the weight gradient of the channel-heavy layers on 8x8 / 16x16 maps and of the 1x1 convs (15 launches, side stream).  Every layer that runs on it is timed
-    in isolation through the C ABI (mmvae_conv2d_wgrad: kernel + partial-image reduce, events on the launch stream), the SLOWEST one is
-    the family's largest instance and is reported against the roofline that bounds it: algorithmic bytes = x + dy (bf16) + the weight
-    gradient (f32), flops = 2 * pixels * Cin * Cout * k^2; bound = mfma when flops / bytes exceeds the bf16 ridge (2.5 PF / 8 TB/s)."""
+def wgrad2_family_roofline(M, device, N, reps=10):
+    """The wgrad2_kernel family: the weight gradient of the channel-heavy layers on 8x8 / 16x16 maps and of the 1x1 convs (side stream).  Every
+    layer that runs on it is timed in isolation through the C ABI (mmvae_conv2d_wgrad: kernel + partial-image reduce, events on the launch
+    stream), the SLOWEST one is the family's largest instance and is reported against the roofline that bounds it: algorithmic bytes = x + dy
+    (bf16) + the weight gradient (f32), flops = 2 * pixels * Cin * Cout * k^2; bound = mfma when flops / bytes exceeds the bf16 ridge
+    (2.5 PF / 8 TB/s)."""
     L = importlib.import_module(PKG + "._lib")
     lib = L.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -228,7 +228,7 @@ def dominant_kernel_roofline(M, device, N, reps=10):
         pix = N * (H * H if tr else Ho * Ho)
         rows.append(dict(layer=name, ms=ms, bytes=(x.numel() + dy.numel()) * 2 + dw.numel() * 4, flop=2.0 * pix * Cin * Cout * k * k))
         del x, dy, dw
-    # the four layers that left the family for wgrad_pos_kernel in round 4, timed the same way (kernel + ordered reduce)
+    # the layers that left the family for wgrad_pos_kernel in round 4, timed the same way (kernel + ordered reduce)
     pos_rows = {}
     for name, tr, Cin, Cout, k, sd, p, H, pro in WGRAD_POS_LAYERS:
         Ho = (H - 1) * sd - 2 * p + k if tr else (H + 2 * p - k) // sd + 1
@@ -271,6 +271,71 @@ def dominant_kernel_roofline(M, device, N, reps=10):
             "achieved_GBs": gbs, "achieved_TFLOPs": tfs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "frac_of_mfma_peak": tfs / MFMA_PEAK_TFLOPS,
             "family_in_step": fam, "family_layers_isolated_ms": {r["layer"]: round(r["ms"], 4) for r in rows},
             "family_isolated_ms_sum": sum(r["ms"] for r in rows), "wgrad_pos_layers_isolated": pos_rows}
+
+
+def convt4_family_roofline(M, device, N, reps=20):
+    """The convT4_stream_kernel family (ConvTranspose2d 16 -> 16, k4 s2 p1 forward as per-wave streams: decoder.uplayer5.conv2 / .upsample at
+    32x32 -> 64x64, uplayer4.conv2 at 16x16 -> 32x32): its largest instance, uplayer5.conv2, timed in isolation through the C ABI (events on the
+    launch stream, weights packed once outside the timed launches).  Algorithmic bytes = input + output activations (bf16) + weights, once."""
+    L = importlib.import_module(PKG + "._lib")
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    rows = {}
+    keep = None
+    for name, H in (("decoder.uplayer5.0.conv2", 32), ("decoder.uplayer5.0.upsample.0", 32), ("decoder.uplayer4.0.conv2", 16)):
+        x = torch.randn(N, H, H, 16, device=device).to(torch.bfloat16)
+        w = torch.randn(16, 16, 4, 4, device=device) * 0.1
+        y = torch.empty(N, 2 * H, 2 * H, 16, device=device, dtype=torch.bfloat16)
+        scratch = torch.empty(2 * w.numel() * 2 + 256, dtype=torch.uint8, device=device)
+        stats = torch.zeros(4096 * 2 * 16, device=device)
+        sc, sh = torch.rand(16, device=device) + 0.5, torch.randn(16, device=device) * 0.1
+        pro = not name.endswith("upsample.0")
+
+        def launch(weights=None):
+            L.check(lib.mmvae_conv2d_fwd(1, 1, L.ptr(x), L.ptr(weights), L.ptr(y), N, H, H, 16, 16, 4, 2, 1, L.ptr(sc) if pro else None,
+                                         L.ptr(sh) if pro else None, 1 if pro else 0, L.ptr(stats), L.ptr(scratch), st), name)
+        launch(w)                                            # packs the weights into `scratch`; the timed launches reuse the pack
+        ms = _time_calls(launch, reps if H == 32 else 6, warm=2)
+        alg = x.numel() * 2 + y.numel() * 2 + w.numel() * 2
+        rows[name] = {"ms": round(ms, 4), "algorithmic_bytes": alg, "GBs": round(alg / (ms * 1e-3) / 1e9, 1)}
+        if keep is None:
+            keep = (ms, alg)
+        del x, y
+    ms, alg = keep
+    ach = alg / (ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic("uplayer5.conv2.fwd", N)
+    top = committed_top_kernels(N)
+    fam = None if top is None else next((f for f in top["families"] if f["family"] == "convT4_stream_kernel"), None)
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "kernel": "convT4_stream_kernel<32> @ decoder.uplayer5.0.conv2 (ConvTranspose2d 16 -> 16 k4 s2, 32x32 -> 64x64 with the fused BatchNorm + ReLU "
+                      "prologue; per-wave stream: input-row ring in LDS, 2x2 taps x 16 channels per MFMA K-step, 16-byte stores, BatchNorm sums in the pass): "
+                      "the largest instance of the step's largest kernel family by GPU time (isolated mmvae_conv2d_fwd launches)",
+            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "achieved_GBs": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBS,
+            "family_in_step": fam, "family_layers_isolated": rows}
+
+
+def dominant_kernel_roofline(M, device, N, reps=10):
+    """`roofline`: the kernel family with the most GPU time per step in the committed kernel statistics (profiles/*_top_kernels.json, taken on
+    THIS build by tools/profile_round.sh) decides which kernel is reported: its largest instance, timed live in isolation.  Round 4: the weight
+    gradients of the channel-heavy layers left wgrad2_kernel for wgrad_pos_kernel one by one, so the family that led rounds 2-3 may no longer
+    lead; the streaming ConvTranspose2d forward is the runner-up.  The weight-gradient table is kept beside it (`wgrad_families`)."""
+    top = committed_top_kernels(N)
+    fams = [] if top is None else [f for f in top["families"] if f.get("ms")]
+    dominant = fams[0]["family"] if fams else "wgrad2_kernel"
+    w2 = wgrad2_family_roofline(M, device, N, reps)
+    if "convT4_stream" in dominant:
+        out = convt4_family_roofline(M, device, N)
+    else:
+        out = dict(w2)
+        if "wgrad2" not in dominant:
+            out["note"] = f"the committed profile's largest family is {dominant}; bench.py has no isolated probe for it: the wgrad2 family is reported"
+    out["dominant_family_in_profile"] = None if not fams else {"family": dominant, "ms": fams[0]["ms"], "launches": fams[0].get("launches"),
+                                                                 "source": top.get("source"), "same_build": top.get("same_build")}
+    if out is not w2:
+        keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "family_in_step", "family_layers_isolated_ms", "family_isolated_ms_sum",
+                "wgrad_pos_layers_isolated")
+        out["wgrad_families"] = {k: w2[k] for k in keys if k in w2}
+    return out
 
 
 def largest_launch_roofline(M, device, N, reps=10):

@@ -121,6 +121,11 @@ MMVAE_API int mmvae_decoder_bwd_gauss(mmvae_net* net, int N, const float* target
  * comes first -- call one of them before anything on `stream` reads the decoder's gradients (optimizer, all-reduce). */
 MMVAE_API int mmvae_net_defer_join(mmvae_net* net, int enable);
 MMVAE_API int mmvae_net_join(mmvae_net* net, void* stream);
+/* The net's side stream, ordered behind everything enqueued on `stream` so far (`stream` itself when the net has none).  Work the caller
+ * enqueues on it runs beside `stream` and is ordered before `stream` again by mmvae_net_join or the next backward entry point that joins
+ * (above).  Used by the host side to take the loss scalars of reference model.py:385-406 (KL, MMD, NLL sums: logged values that no
+ * gradient kernel reads) off the critical stream of a train step. */
+MMVAE_API void* mmvae_net_fork(mmvae_net* net, void* stream);
 
 /* SyncBN: BatchNorm statistics over the global batch of a data-parallel job.  `fn` must SUM the `n` f32 values at
  * device pointer `buf` over all ranks in place, ordered on `stream` (the caller's stream or the net's side stream), and return 0;

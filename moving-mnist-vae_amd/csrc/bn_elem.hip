@@ -154,14 +154,28 @@ int launch_partial_rowsum(const float* partials, int nparts, int width, float* o
 }
 
 // ---------------------------------------------------------------- finalize (training)
+// Two strided column sums over per-block partial rows (finalize kernels: one block per channel).  The loads of U rows are issued before the
+// first add, so a block pays nparts / (U * blockDim) memory latencies instead of nparts / blockDim -- these launches sit between the big
+// kernels of the critical stream.  Fixed order per thread -> bit-reproducible.
+template <int U>
+__device__ __forceinline__ void strided_pair_sum(const float* __restrict__ pa, const float* __restrict__ pb, long stride, int nparts, double& s0, double& s1) {
+  const int bd = blockDim.x;
+  int p = threadIdx.x;
+  for (; p + (U - 1) * bd < nparts; p += U * bd) {
+    float va[U], vb[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) { va[k] = pa[(long)(p + k * bd) * stride]; vb[k] = pb[(long)(p + k * bd) * stride]; }
+#pragma unroll
+    for (int k = 0; k < U; ++k) { s0 += (double)va[k]; s1 += (double)vb[k]; }
+  }
+  for (; p < nparts; p += bd) { s0 += (double)pa[(long)p * stride]; s1 += (double)pb[(long)p * stride]; }
+}
+
 __global__ void bn_finalize_kernel(BnFinalizeArgs a) {
   __shared__ double sRed[2 * 4];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int p = threadIdx.x; p < a.nparts; p += blockDim.x) {
-    s1 += (double)a.partials[(long)p * 2 * a.C + c];
-    s2 += (double)a.partials[(long)p * 2 * a.C + a.C + c];
-  }
+  strided_pair_sum<8>(a.partials + c, a.partials + a.C + c, 2L * a.C, a.nparts, s1, s2);
   s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { sRed[wid] = s1; sRed[4 + wid] = s2; }
@@ -350,10 +364,7 @@ __global__ void bn_bwd_finalize_kernel(BnBwdFinalizeArgs a0, BnBwdFinalizeArgs a
   const int c = blockIdx.x;
   const int rows = 1 + a.ny;
   double s0 = 0.0, s1 = 0.0;
-  for (int p = threadIdx.x; p < a.nparts; p += blockDim.x) {
-    s0 += (double)a.partials[((long)p * rows) * a.C + c];
-    s1 += (double)a.partials[((long)p * rows + 1 + a.which) * a.C + c];
-  }
+  strided_pair_sum<8>(a.partials + c, a.partials + (long)(1 + a.which) * a.C + c, (long)rows * a.C, a.nparts, s0, s1);
   s0 = wave_sum_d(s0); s1 = wave_sum_d(s1);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) { sRed[wid] = s0; sRed[4 + wid] = s1; }

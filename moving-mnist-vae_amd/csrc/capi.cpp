@@ -120,6 +120,11 @@ int mmvae_net_join(mmvae_net* n, void* stream) {
   return n->net->join(S(stream));
 }
 
+void* mmvae_net_fork(mmvae_net* n, void* stream) {
+  if (!n) return stream;
+  return reinterpret_cast<void*>(n->net->fork(S(stream)));
+}
+
 int mmvae_net_set_sync_bn(mmvae_net* n, mmvae_allreduce_fn fn, void* user, int world) {
   if (!n || (fn && world < 1)) { set_error("net_set_sync_bn: bad argument"); return MMVAE_ERR_ARG; }
   n->net->set_sync_bn(reinterpret_cast<mmvae::Net::AllReduceFn>(fn), user, world);

@@ -333,36 +333,39 @@ struct StemBwdFinArgs {
   float* dgamma; float* dbeta; float* dW;       // dW [32][25]  (+=)
 };
 
-__global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(StemBwdFinArgs a) {
-  __shared__ double sB[2][4];
-  __shared__ double sW[8][32];
+// 1024 threads: 32 part-lanes x 32 taps; every thread's loads are independent (24 rows each at 768 partial rows, 8 accumulators), so the
+// kernel costs a few memory latencies instead of a dependent chain of them (it sits at the very end of the step's critical stream)
+__global__ __launch_bounds__(1024) void stem_bwd_finalize_kernel(StemBwdFinArgs a) {
+  __shared__ double sB[2][16];
+  __shared__ double sW[32][32];
   __shared__ double sR[26 * 32];
   __shared__ float sw[25];
   const int c = blockIdx.x, t = threadIdx.x;
-  for (int i = t; i < 26 * 32; i += 256) sR[i] = a.R[i];
+  for (int i = t; i < 26 * 32; i += 1024) sR[i] = a.R[i];
   if (t < 25) sw[t] = a.w[c * 25 + t];
   double b0 = 0.0, b1 = 0.0;
-  for (int p = t; p < a.nparts; p += 256) {
+  for (int p = t; p < a.nparts; p += 1024) {
     const float* row = a.partials + (long)p * kStemPartFloats;
     b0 += (double)row[c]; b1 += (double)row[32 + c];
   }
   b0 = wave_sum_d(b0); b1 = wave_sum_d(b1);
   if ((t & 63) == 0) { sB[0][t >> 6] = b0; sB[1][t >> 6] = b1; }
-  // W1[c][tap]: 8 part-lanes per tap, 8 independent loads in flight each
+  // W1[c][tap]: 32 part-lanes per tap, 8 independent loads in flight each
   const int pl = t >> 5, tap = t & 31;
   const float* src = a.partials + 64 + c * 32 + tap;
   double w1[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) w1[k] = 0.0;
   int p = pl;
-  for (; p + 56 < a.nparts; p += 64) {
+  for (; p + 224 < a.nparts; p += 256) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) w1[k] += (double)src[(long)(p + 8 * k) * kStemPartFloats];
+    for (int k = 0; k < 8; ++k) w1[k] += (double)src[(long)(p + 32 * k) * kStemPartFloats];
   }
-  for (; p < a.nparts; p += 8) w1[0] += (double)src[(long)p * kStemPartFloats];
+  for (; p < a.nparts; p += 32) w1[0] += (double)src[(long)p * kStemPartFloats];
   sW[pl][tap] = ((w1[0] + w1[1]) + (w1[2] + w1[3])) + ((w1[4] + w1[5]) + (w1[6] + w1[7]));
   __syncthreads();
-  const double S0 = (sB[0][0] + sB[0][1]) + (sB[0][2] + sB[0][3]), S1 = (sB[1][0] + sB[1][1]) + (sB[1][2] + sB[1][3]);
+  double S0 = 0.0, S1 = 0.0;
+  for (int q = 0; q < 16; ++q) { S0 += sB[0][q]; S1 += sB[1][q]; }
   const double mean = a.mean[c], istd = a.istd[c], g = a.gamma ? a.gamma[c] : 1.0;
   const double sgy_local = istd * (S1 - mean * S0);
   if (t == 0) {
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(StemBwdFinArgs a
   const double m1 = G0 / a.count, m2 = sgy / a.count, A = g * istd;
   if (t < 25) {
     double v1 = 0.0;
-    for (int q = 0; q < 8; ++q) v1 += sW[q][t];
+    for (int q = 0; q < 32; ++q) v1 += sW[q][t];
     double v2 = 0.0;                                   // sum_pix y0[c] * patch[t] = sum_t' w[c][t'] * R[t'][t]
     for (int u = 0; u < 25; ++u) v2 += (double)sw[u] * sR[u * 32 + t];
     const double v3 = sR[25 * 32 + t];
@@ -579,7 +582,7 @@ int launch_stem_bwd_dg(const void* dy1, const void* dys, const void* wd1, const 
 int launch_stem_bwd_finalize(const float* partials, int nparts, const double* R, const float* w, const float* global_sums, double count,
                              const float* gamma, const float* mean, const float* istd, float* dgamma, float* dbeta, float* dW, hipStream_t s) {
   StemBwdFinArgs a{partials, nparts, R, w, global_sums, count, gamma, mean, istd, dgamma, dbeta, dW};
-  hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(32), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(stem_bwd_finalize_kernel, dim3(32), dim3(1024), 0, s, a);
   return check_launch("stem_bwd_finalize");
 }
 

@@ -186,15 +186,23 @@ class _PixelFn(torch.autograd.Function):
 
 
 class _StepScalars:
-    """The four scalars of one step (loss, nll/N, kl/N, mmd/N) as a device tensor, copied to the host on first use."""
-    __slots__ = ("dev", "vals")
+    """The four scalars of one step (loss, nll/N, kl/N, mmd/N) as a device tensor, copied to the host on first use.  `join` (optional):
+    orders the stream that produced them (the net's side stream, _LossFn) before the current one -- called before any read."""
+    __slots__ = ("dev", "vals", "join")
 
-    def __init__(self, dev_tensor):
-        self.dev, self.vals = dev_tensor, None
+    def __init__(self, dev_tensor, join=None):
+        self.dev, self.vals, self.join = dev_tensor, None, join
+
+    def ready(self):
+        """The device tensor, ordered before the current stream."""
+        if self.join is not None:
+            self.join()
+            self.join = None
+        return self.dev
 
     def get(self, i):
         if self.vals is None:
-            self.vals = self.dev.tolist()        # the only device->host copy (and synchronisation) of the step
+            self.vals = self.ready().tolist()    # the only device->host copy (and synchronisation) of the step
         return self.vals[i]
 
 
@@ -272,6 +280,14 @@ class _LossFn(torch.autograd.Function):
         acc = torch.zeros(4, dtype=torch.float64, device=dev)      # px, kl, mmd
         out = torch.empty(4, dtype=torch.float32, device=dev)      # loss, px/N, kl/N, mmd/N
         st = _stream()
+        # `model._loss_side` (set by VAE.loss(deferred=True) inside a train step): the loss scalars are logged values -- no gradient kernel
+        # reads them -- so their kernels (KL, MMD, NLL / CE sums, the combine) run on the net's side stream beside the backward pass that the
+        # host enqueues next; the stream is ordered before the caller's again by the backward pass's own join (mmvae_encoder_bwd /
+        # mmvae_net_join) or by the first read of the scalars (_StepScalars.ready).  Every operand stays alive in ctx until then.
+        side = bool(model.__dict__.get("_loss_side")) and model._h is not None
+        model.__dict__["_loss_side"] = False
+        if side:
+            st = L.mmvae_net_fork(model._h, st)
         base = acc.data_ptr()
         recon = recon.contiguous()
         categorical = model.pixelcnn is not None or model.decoder_out_channels > model.in_channels      # model.py:398
@@ -282,6 +298,7 @@ class _LossFn(torch.autograd.Function):
             encoding = encoding.contiguous()
             scratch = torch.empty(2 * N, dtype=torch.float32, device=dev)
             check(L.mmvae_mmd_fwd(ptr(true_samples), ptr(encoding), N, encoding.shape[1], ptr(scratch), base + 16, st), "mmvae_mmd_fwd")
+            ctx.keep = (scratch, acc)
         if categorical:
             target = target.contiguous()
             Q, HW = recon.shape[1], recon.shape[2] * recon.shape[3]
@@ -291,7 +308,10 @@ class _LossFn(torch.autograd.Function):
             check(L.mmvae_gauss_nll_fwd(ptr(recon), ptr(target), recon.numel(), float(model.sigma_decoder), base, st), "mmvae_gauss_nll_fwd")
         check(L.mmvae_loss_finish(base, ptr(out), float(model.nll), float(model.kl), float(model.mmd), float(N), st), "mmvae_loss_finish")
         model._last_scalars = out
+        model.__dict__["_last_on_side"] = side
         ctx.model, ctx.N, ctx.categorical = model, N, categorical
+        if side and not hasattr(ctx, "keep"):
+            ctx.keep = (acc,)
         # the reconstruction is the decoder's own output tensor (no crop, no copy): its gradient can be folded into the decoder's backward
         lr = model._last_recon
         ctx.direct_tail = (lr[1] if (lr is not None and lr[0] == recon.data_ptr() and not categorical and model.fuse_loss_tail and
@@ -765,8 +785,14 @@ class VAE(nn.Module):
                 weight = weight.to(dev).contiguous().float()
             if target.dtype != torch.int64:
                 target = target.long()
+        # the side-stream form needs the backward pass that follows to join it (and to keep the operands alive): train steps only
+        self.__dict__["_loss_side"] = bool(deferred and self.training and torch.is_grad_enabled() and reconstruction.requires_grad and self._h is not None)
         loss_t = _LossFn.apply(self, target, encoding_mu, encoding_logvar, enc2, reconstruction, ts, weight)
-        grp = _StepScalars(self._last_scalars)
+        join = None
+        if self.__dict__.get("_last_on_side"):
+            net = self                          # (keeps the net alive until the scalars have been read)
+            join = lambda: check(lib().mmvae_net_join(net._h, _stream()), "mmvae_net_join")
+        grp = _StepScalars(self._last_scalars, join)
         self._last_group = grp
         if deferred:
             return loss_t, DeferredScalar(grp, 1), DeferredScalar(grp, 2), DeferredScalar(grp, 3)
@@ -1106,7 +1132,7 @@ class GradSync:
         ranks.  `groups` are the _StepScalars of the steps not yet read back."""
         if self.world == 1 or not groups:
             return
-        stacked = torch.stack([g.dev for g in groups]).contiguous()
+        stacked = torch.stack([g.ready() for g in groups]).contiguous()
         if self.comm is not None:
             self.comm.all_reduce_(stacked)
         else:

@@ -7,6 +7,7 @@ keys: uplayer5.conv2.fwd   the last convT4_stream_kernel (else patch_conv_kernel
       (decoder.uplayer5.0.conv2 forward)
       uplayer5.join_bwd   the last up-block's backward in one pass (join_bwd_stream_kernel); builds without it:
       uplayer5.join_bwd_apply = the apply pass of the join backward (tail_apply_mfma_kernel, else the second tail_join_bwd_kernel dispatch)
+      wgrad2.<layer>   a wgrad2_kernel dispatch + its wgrad_reduce_kernel, for the five layers named in pick()
       __step__   every dispatch of the last train step (between two Adam kernels)
 usage: python tools/pmc_hbm_csv.py <fetch counter_collection.csv> <write counter_collection.csv> <frames> > profiles/rNN_pmc_hbm.csv"""
 import csv
@@ -44,14 +45,16 @@ def pick(step):
     jb = [k for k, n in enumerate(names) if "join_bwd_stream_kernel" in n]
     ta = [k for k, n in enumerate(names) if "tail_apply_mfma_kernel" in n]
     tb = [k for k, n in enumerate(names) if "tail_join_bwd_kernel" in n]
-    # the wgrad2 family's longest instance (bench.py's `roofline`): the step issues its 19 wgrad2 launches in a fixed order -- decoder
-    # uplayer3..1 (conv2, upsample, conv1 each), decoder.conv1, the two heads, encoder layer4..2 (conv2, downsample, conv1 each; one of
-    # them on the first-generation kernel) -- encoder.layer4.0.conv2 is the 12th; its partial-image reduce is the next wgrad_reduce
+    # the wgrad2 family (bench.py's weight-gradient table): the step issues its 11 wgrad2 launches in a fixed order that starts with
+    # decoder.uplayer3 (conv2, upsample, conv1) and ends with encoder.layer2 (conv2, downsample, conv1) -- the candidates for the family's
+    # slowest instance are the first two and the last three.  Each launch's partial-image reduce is the next wgrad_reduce dispatch.
     w2 = [k for k, n in enumerate(names) if "wgrad2_kernel" in n]
-    if len(w2) == 19:
-        k = w2[11]
-        red = next((q for q in range(k + 1, len(names)) if "wgrad_reduce_kernel" in names[q]), None)
-        out["wgrad2.encoder.layer4.0.conv2"] = step[k][1] + (step[red][1] if red is not None else 0.0)
+    if len(w2) == 11:
+        for idx, layer in ((0, "decoder.uplayer3.0.conv2"), (1, "decoder.uplayer3.0.upsample.0"), (-3, "encoder.layer2.0.conv2"),
+                           (-2, "encoder.layer2.0.downsample.0"), (-1, "encoder.layer2.0.conv1")):
+            k = w2[idx]
+            red = next((q for q in range(k + 1, len(names)) if "wgrad_reduce_kernel" in names[q]), None)
+            out["wgrad2." + layer] = step[k][1] + (step[red][1] if red is not None else 0.0)
     if jb:
         out["uplayer5.join_bwd"] = step[jb[0]][1]
     elif ta or len(tb) > 1:
@@ -64,8 +67,8 @@ def main(fetch_csv, write_csv, frames):
     f = pick(last_step(per_dispatch(fetch_csv, "FETCH_SIZE")))
     w = pick(last_step(per_dispatch(write_csv, "WRITE_SIZE")))
     print("build,frames,key,fetch_bytes,write_bytes")
-    for k in ("uplayer5.conv2.fwd", "uplayer5.join_bwd", "uplayer5.join_bwd_apply", "wgrad2.encoder.layer4.0.conv2", "__step__"):
-        if k in f:
+    for k in f:
+        if k in w:
             print(f"{build},{int(frames)},{k},{2 * f[k] * 1024:.0f},{w[k] * 1024:.0f}")
 
 
