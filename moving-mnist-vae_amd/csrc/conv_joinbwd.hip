@@ -424,7 +424,9 @@ struct Conv1BwdArgs {
   long nrows;                                               // N * Hp rows of 32 pixels
 };
 
-template <bool PRO_X>
+// MASK: g_in leaves multiplied by [pro(xin) > 0] -- xin is the output of the block below's join ReLU, so that block's BatchNorm backward
+// needs no mask pass (its reduce runs unmasked, its dy is evaluated by the consumers' loaders: wgrad_stream_kernel JG)
+template <bool PRO_X, bool MASK>
 __global__ __launch_bounds__(256, 4) void conv1_bwd_stream_kernel(Conv1BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), gq = lane >> 4, r = lane & 15;
@@ -489,6 +491,12 @@ __global__ __launch_bounds__(256, 4) void conv1_bwd_stream_kernel(Conv1BwdArgs a
       const uint2 e = g0[pt];
       float v[4] = {dg[0] + __uint_as_float(e.x << 16), dg[1] + __uint_as_float(e.x & 0xffff0000u), dg[2] + __uint_as_float(e.y << 16),
                     dg[3] + __uint_as_float(e.y & 0xffff0000u)};
+      if constexpr (MASK) {
+        const uint2 xr = *reinterpret_cast<const uint2*>(xrow + (16 * pt + r) * 32 + gq * 8);          // pro(xin)[pixel][4gq .. 4gq+3]
+        const float xm[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = xm[j] > 0.f ? v[j] : 0.f;
+      }
       dstore4<bf16_t>(reinterpret_cast<bf16_t*>(a.gin) + cur * 512 + (16 * pt + r) * 16 + 4 * gq, v, false);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -515,8 +523,13 @@ int launch_conv1_bwd_stream(const Conv1BwdLaunch& L, hipStream_t s) {
   int gx = 1024;
   while (gx > 8 && (long)gx * 4 > a.nrows) gx -= 8;
   note_launch_bytes((double)L.nrows * 1024.0 * 5);         // d_a1, y1, xin, g_in read; g_in written
-  if (L.pxs) hipLaunchKernelGGL(conv1_bwd_stream_kernel<true>, dim3(gx), dim3(256), 4 * 2048, s, a);
-  else hipLaunchKernelGGL(conv1_bwd_stream_kernel<false>, dim3(gx), dim3(256), 4 * 2048, s, a);
+  if (L.pxs) {
+    if (L.mask_out) hipLaunchKernelGGL((conv1_bwd_stream_kernel<true, true>), dim3(gx), dim3(256), 4 * 2048, s, a);
+    else hipLaunchKernelGGL((conv1_bwd_stream_kernel<true, false>), dim3(gx), dim3(256), 4 * 2048, s, a);
+  } else {
+    if (L.mask_out) hipLaunchKernelGGL((conv1_bwd_stream_kernel<false, true>), dim3(gx), dim3(256), 4 * 2048, s, a);
+    else hipLaunchKernelGGL((conv1_bwd_stream_kernel<false, false>), dim3(gx), dim3(256), 4 * 2048, s, a);
+  }
   const int rc = check_launch("conv1_bwd_stream");
   return rc ? rc : gx;
 }

@@ -192,12 +192,21 @@ bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, in
 
 int op_run_bwd_fused(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                      const void* G, int Hl, int Wl, const void* packed_down, void* dP, const void* x2, const void* w2_packed, float* dW,
-                     hipStream_t s, float* scratch, float scale, float* bn_part, float* dW2, float scale2) {
+                     hipStream_t s, float* scratch, float scale, float* bn_part, float* dW2, float scale2, const JoinGrad* jg) {
   if (g.k * g.k > 25) return 0;
   WgradArgs a;
   wgrad_args(a, g, N, P, Hs, Ws, proP_s, proP_b, proP_relu, G, Hl, Wl, nullptr, nullptr, 0, dW, scratch, scale);
   a.M = a.N * a.Hp * a.Wp;
-  return try_dgrad_wgrad_stream(dt, a, packed_down, dP, x2, w2_packed, bn_part, s, dW2, scale2);
+  return try_dgrad_wgrad_stream(dt, a, packed_down, dP, x2, w2_packed, bn_part, s, dW2, scale2, jg);
+}
+
+// whether op_run_bwd_fused takes this layer with a JoinGrad (see kernels.hpp)
+bool op_bwd_fusable_jg(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl, bool proP, bool has_x2, bool bn_sums) {
+  if (g.k * g.k > 25) return false;
+  WgradArgs a;
+  float dummy = 0.f;
+  wgrad_args(a, g, N, nullptr, Hs, Ws, proP ? &dummy : nullptr, proP ? &dummy : nullptr, 1, nullptr, Hl, Wl, nullptr, nullptr, 0, nullptr, &dummy, 1.f);
+  return dgrad_wgrad_stream_jg_shape(dt, a, has_x2, bn_sums);
 }
 
 }  // namespace mmvae

@@ -53,6 +53,11 @@ int op_run_wgrad_pair(int dt, const ConvGeom& g, const ConvGeom& gs, int N, cons
 bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl);
 int op_run_bwd_fused(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                      const void* G, int Hl, int Wl, const void* packed_down, void* dP, const void* x2, const void* w2_packed, float* dW,
-                     hipStream_t s, float* scratch, float scale = 1.f, float* bn_part = nullptr, float* dW2 = nullptr, float scale2 = 1.f);
+                     hipStream_t s, float* scratch, float scale = 1.f, float* bn_part = nullptr, float* dW2 = nullptr, float scale2 = 1.f,
+                     const JoinGrad* jg = nullptr);
+// jg (optional): G is the masked gradient of a residual join's output and the layer's dy is evaluated on load (kernels.hpp, JoinGrad) -- no
+// bn_bwd_apply pass, no dy tensor.  op_bwd_fusable_jg: whether that form exists for the layer (16-wide maps; conv2 with prologue + BatchNorm sums,
+// or the 32-channel shortcut with the 1x1 conv's second source).
+bool op_bwd_fusable_jg(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl, bool proP, bool has_x2, bool bn_sums);
 
 }  // namespace mmvae

@@ -40,6 +40,10 @@ struct WStreamArgs {
   // shortcut next to a 3x3 stride-S conv (encoder.layer1: conv1 and downsample.0 from one read of the block input).  Its weight gradient
   // dW2[a][b] = sum P2[n,h,w,a] * G[n, S*h, S*w, b] is one more image of the partial, [NT + 1][CA][CB]
   const void* P2;
+  // (JG) G is the dy of a BatchNorm after a residual join, evaluated on load instead of read: G = jA[c] * dout + jB[c] * Jy + jC[c], dout
+  // (a.G) the gradient w.r.t. the join's output ALREADY masked by its ReLU, Jy the branch's pre-BatchNorm output -- the bn_bwd_apply launch
+  // that would write dy (and the read of it here) disappears
+  const void* Jy; const float* jA; const float* jB; const float* jC;
 };
 
 // KS x KS taps, stride S, padding PAD; WP = P row width: one step = 32 P pixels = one MFMA K-step = ONE row of 32 or TWO rows of 16
@@ -54,8 +58,9 @@ struct WStreamArgs {
 // ST (with DG and PRO_P): P is a pre-BatchNorm tensor whose BN+ReLU is the prologue; the pass also reduces that BatchNorm's backward sums
 // (sum g, sum g*P over all pixels, g = dx masked by the ReLU) from the data gradient it has just computed -- the bn_bwd_reduce launch
 // that would re-read dx and P disappears.
-template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST, int NW = 4, bool P2 = false>
+template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST, int NW = 4, bool P2 = false, bool JG = false>
 __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a) {
+  static_assert(!JG || (DG && !PRO_G), "the join-gradient loader rides on the fused data-gradient pass");
   static_assert(WP == 32 || WP == 16, "32 P pixels per step: one row of 32 or two rows of 16");
   static_assert(!ST || (DG && PRO_P && !X2 && CA16 == 1), "BatchNorm sums ride on the data gradient of a prologue'd 16-channel P");
   static_assert(!DG || (CB16 == 1 && KS == 4 && S == 2), "fused data gradient: 16 G channels, 4x4 taps, stride 2");
@@ -119,6 +124,13 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gsc[j] = a.proG_scale[c + j]; gsh[j] = a.proG_shift[c + j]; }
   }
+  // (JG) the coefficient table [3][CB] sits behind the rings in LDS and is read where a row is committed: 24 registers live for a few
+  // instructions instead of the whole loop (the 32-channel second-source form is at the 256-register limit)
+  float* jtab = reinterpret_cast<float*>(smem + WDB + NW * WAVE_LDS);
+  if constexpr (JG) {
+    if (t < CB) { jtab[t] = a.jA[t]; jtab[CB + t] = a.jB[t]; jtab[2 * CB + t] = a.jC[t]; }
+    __syncthreads();
+  }
   const float p_lo = a.proP_relu ? 0.f : -__builtin_inff(), g_lo = a.proG_relu ? 0.f : -__builtin_inff();
   // ---- fragment offsets (tile-invariant): k-slice gq = the step's P pixels 8gq .. 8gq+7, two 4-pixel blocks; lane i = r supplies the
   // address of pixel (i >> 2) of the block, channel quad (i & 3).  With two rows per step the slice's row is (8 gq) / WP.
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
   const int nq = a.HS / RP + 1;                             // steps of a unit: the priming step + one per RP P rows
 
   // registers of the step in flight
-  Vec16 gv[GV], pv[PV], pv2[P2 ? PV : 1], xv = Vec16{{0, 0, 0, 0}};
+  Vec16 gv[GV], jv[JG ? GV : 1], pv[PV], pv2[P2 ? PV : 1], xv = Vec16{{0, 0, 0, 0}};
   auto issue = [&](int u, int q) {
     const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
     const int hrow = h0 + RP * (q - 1);                     // first P row of the step (q = 0: the rows above the strip's first step)
@@ -192,8 +204,11 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
       const int rr = byte / grow_bytes, off = byte - rr * grow_bytes;
       const int row = top - GR + 1 + rr;
       gv[k] = Vec16{{0, 0, 0, 0}};
-      if (rr < GR && row >= 0 && row < a.Hg)
+      if constexpr (JG) jv[k] = Vec16{{0, 0, 0, 0}};
+      if (rr < GR && row >= 0 && row < a.Hg) {
         gv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(Gm) + (((long)n * a.Hg + row) * Wg) * CBB + off);
+        if constexpr (JG) jv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.Jy) + (((long)n * a.Hg + row) * Wg) * CBB + off);
+      }
     }
     if (q > 0) {
 #pragma unroll
@@ -222,6 +237,22 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
           Elem<bf16_t>::unpack(v, f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * gsc[j] + gsh[j], g_lo);
+          v = Elem<bf16_t>::pack(f);
+        }
+        if constexpr (JG) if (row >= 0 && row < a.Hg) {        // (rows outside the map stay zero: they are the conv's padding)
+          float f[8], y[8];
+          Elem<bf16_t>::unpack(v, f);
+          Elem<bf16_t>::unpack(jv[k], y);
+          const int c = (lane % (CBB / 16)) * 8;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 cA = *reinterpret_cast<const float4*>(jtab + c + 4 * h), cB = *reinterpret_cast<const float4*>(jtab + CB + c + 4 * h),
+                         cC = *reinterpret_cast<const float4*>(jtab + 2 * CB + c + 4 * h);
+            f[4 * h + 0] = cA.x * f[4 * h + 0] + cB.x * y[4 * h + 0] + cC.x;
+            f[4 * h + 1] = cA.y * f[4 * h + 1] + cB.y * y[4 * h + 1] + cC.y;
+            f[4 * h + 2] = cA.z * f[4 * h + 2] + cB.z * y[4 * h + 2] + cC.z;
+            f[4 * h + 3] = cA.w * f[4 * h + 3] + cB.w * y[4 * h + 3] + cC.w;
+          }
           v = Elem<bf16_t>::pack(f);
         }
         const int slot = (row + 4 * NSLOT) % NSLOT;
@@ -431,17 +462,17 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
   for (int i = t; i < WSIZE / 4; i += 64 * NW) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(img)[i];
 }
 
-template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST = false, int NW = 4, bool P2 = false>
+template <int KS, int S, int PAD, int WP, int CA16, int CB16, bool PRO_P, bool PRO_G, bool DG, bool X2, bool ST = false, int NW = 4, bool P2 = false, bool JG = false>
 static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
   constexpr int RP = 32 / WP;
   constexpr int WL = S * (WP - 1) + KS;
   constexpr int NSLOT = S * (RP - 1) + KS + S * RP;
   constexpr size_t rings = NW * (size_t)(NSLOT * WL * CB16 * 32 + 32 * CA16 * 32 + (X2 ? 32 * 32 : 0) + (ST ? 32 * CA16 * 32 : 0) + (P2 ? 32 * CA16 * 32 : 0)) +
-                           ((DG && CA16 > 1) ? CA16 * (KS * KS / 2) * 1024 : 0);
+                           ((DG && CA16 > 1) ? CA16 * (KS * KS / 2) * 1024 : 0) + (JG ? 3 * CB16 * 16 * 4 : 0);
   constexpr size_t flush = ((size_t)KS * KS * CA16 * 16 * CB16 * 16 + (X2 ? 16 * CA16 * 16 : 0) + (P2 ? CA16 * 16 * CB16 * 16 : 0)) * 4 + 512;
   constexpr size_t lds = rings > flush ? rings : flush;
   static_assert(lds <= 160 * 1024, "one block must fit the CU's LDS");
-  auto kern = &wgrad_stream_kernel<KS, S, PAD, WP, CA16, CB16, PRO_P, PRO_G, DG, X2, ST, NW, P2>;
+  auto kern = &wgrad_stream_kernel<KS, S, PAD, WP, CA16, CB16, PRO_P, PRO_G, DG, X2, ST, NW, P2, JG>;
   static bool attr_set = false;
   if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -567,16 +598,24 @@ bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a) {
   const int kind = wstream_kind(dt, a);
   return enabled != 0 && (kind == 1 || kind == 2) && !a.proG_scale;
 }
+// jg (optional): G is the join's masked output gradient and dy = jg->A * G + jg->B * jg->y + jg->C is evaluated on load (JG above); the
+// instantiated forms are the two a DeconvBottleneck on 16-wide maps needs: (Ca 16, prologue, BatchNorm sums) and (Ca 32, second source).
+bool dgrad_wgrad_stream_jg_shape(int dt, const WgradArgs& a, bool has_x2, bool bn_sums) {
+  if (!dgrad_wgrad_stream_shape(dt, a) || wstream_kind(dt, a) != 2) return false;
+  return (a.Ca == 16 && a.proP_scale && bn_sums && !has_x2) || (a.Ca == 32 && !a.proP_scale && has_x2 && !bn_sums);
+}
 int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s,
-                           float* dW2, float scale2) {
+                           float* dW2, float scale2, const JoinGrad* jg) {
   if (!dgrad_wgrad_stream_shape(dt, a) || !wd || !dx || ((x2 != nullptr) != (w2 != nullptr))) return 0;
+  if (jg && !dgrad_wgrad_stream_jg_shape(dt, a, x2 != nullptr, bn_part != nullptr)) { set_error("dgrad_wgrad_stream: no join-gradient form of this shape"); return MMVAE_ERR_UNSUPPORTED; }
   if (bn_part && (x2 || !a.proP_scale || a.Ca != 16)) { set_error("dgrad_wgrad_stream: BatchNorm sums need the prologue'd 16-channel P and no second source"); return MMVAE_ERR_ARG; }
   const int kind = wstream_kind(dt, a);
   WStreamArgs b;
   const int gx = wstream_fill(a, b, kind, x2 != nullptr);
   if (gx <= 0) return 0;
   b.wd = wd; b.dx = dx; b.x2 = x2; b.w2 = w2; b.bn_part = bn_part;
-  note_launch_bytes((double)a.N * 2.0 * ((double)a.Hp * a.Wp * (2 * a.Ca + (x2 ? 16 : 0)) + (double)a.Hg * a.Wg * a.Cb));     // P, dx, x2, G (bf16)
+  if (jg) { b.Jy = jg->y; b.jA = jg->A; b.jB = jg->B; b.jC = jg->C; }
+  note_launch_bytes((double)a.N * 2.0 * ((double)a.Hp * a.Wp * (2 * a.Ca + (x2 ? 16 : 0)) + (double)a.Hg * a.Wg * a.Cb * (jg ? 2 : 1)));   // P, dx, x2, G (+ Jy) (bf16)
   const bool pp = a.proP_scale != nullptr;
   int rc;
 #define MMVAE_WSD(WP, CA)                                                                                                    \
@@ -586,7 +625,9 @@ int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx,
     else rc = pp ? launch_wstream_t<4, 2, 1, WP, CA, 1, true, false, true, false>(b, gx, s)                                   \
                  : launch_wstream_t<4, 2, 1, WP, CA, 1, false, false, true, false>(b, gx, s);                                 \
   } while (0)
-  if (bn_part) rc = kind == 1 ? launch_wstream_t<4, 2, 1, 32, 1, 1, true, false, true, false, true>(b, gx, s)
+  if (jg) rc = bn_part ? launch_wstream_t<4, 2, 1, 16, 1, 1, true, false, true, false, true, 4, false, true>(b, gx, s)
+                       : launch_wstream_t<4, 2, 1, 16, 2, 1, false, false, true, true, false, 4, false, true>(b, gx, s);
+  else if (bn_part) rc = kind == 1 ? launch_wstream_t<4, 2, 1, 32, 1, 1, true, false, true, false, true>(b, gx, s)
                               : launch_wstream_t<4, 2, 1, 16, 1, 1, true, false, true, false, true>(b, gx, s);
   else if (kind == 1) { if (a.Ca == 16) MMVAE_WSD(32, 1); else MMVAE_WSD(32, 2); }
   else { if (a.Ca == 16) MMVAE_WSD(16, 1); else MMVAE_WSD(16, 2); }

@@ -75,8 +75,12 @@ int try_wgrad_stream_pair(int dt, const WgradArgs& a, const void* P2, float* dW2
 // weight gradient + data gradient (w.r.t. P) of a 16 -> 16 channel k4 s2 layer in one pass over G (conv_wstream.hip)
 bool dgrad_wgrad_stream_shape(int dt, const WgradArgs& a);
 // dW2 (optional, with x2): the 1x1 conv's own weight gradient [16][Ca] += scale2 * x2^T (x) pro(P), from the same pass
+// dy of a BatchNorm behind a residual join, evaluated by the consumer's loader: dy = A[c] * g + B[c] * y + C[c], g = the join's output gradient
+// already masked by its ReLU, y = the branch's pre-BatchNorm output (conv_wstream.hip, JG)
+struct JoinGrad { const void* y; const float* A; const float* B; const float* C; };
+bool dgrad_wgrad_stream_jg_shape(int dt, const WgradArgs& a, bool has_x2, bool bn_sums);
 int try_dgrad_wgrad_stream(int dt, const WgradArgs& a, const void* wd, void* dx, const void* x2, const void* w2, float* bn_part, hipStream_t s,
-                           float* dW2 = nullptr, float scale2 = 1.f);
+                           float* dW2 = nullptr, float scale2 = 1.f, const JoinGrad* jg = nullptr);
 
 // ---- last up-block backward in one pass (conv_joinbwd.hip): the join's BatchNorm backward (incoming gradient recomputed from the
 // one-plane reconstruction gradient), both ConvTranspose2d weight gradients and data gradients, bn1's backward sums -- dy2 / dys are
@@ -97,6 +101,7 @@ int launch_join_bwd_stream(const JoinBwdLaunch& L, hipStream_t s);    // returns
 struct Conv1BwdLaunch {
   const void* da1; const void* y1; const float* ms; const float* mb; const float* A; const float* B; const float* C;
   const void* xin; const float* pxs; const float* pxb; const void* w1u; void* gin; float* part; long nrows;
+  int mask_out = 0;   // g_in leaves masked by the ReLU that produced xin (xin > 0): the block below evaluates its BatchNorm backward on load (JoinGrad)
 };
 int launch_conv1_bwd_stream(const Conv1BwdLaunch& L, hipStream_t s);  // returns blocks
 

@@ -1019,8 +1019,21 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     MM_TRY(launch_gather_gemm(dt(), dt(), a, s));
   }
   const int nd = (int)dec.size();
+  // Join-gradient form of a block's backward (blocks on 16-wide maps, uplayer4): the block above hands down its input gradient already masked
+  // by this block's join ReLU (conv1_bwd_stream_kernel, MASK), the BatchNorm-backward reduce runs unmasked, and dy2 / dys are evaluated by the
+  // loaders of the two fused ConvTranspose2d backward passes -- the bn_bwd_apply launch (840 MB at N = 5120) and both dy tensors disappear.
+  auto jg_block = [&](int j) {
+    if (j < 0 || j >= nd || dt() != DT_BF16) return false;
+    const Block& Bj = dec[j];
+    if (Bj.identity || Bj.C != 16 || Bj.c2.fp8 || Bj.cs.fp8 || Bj.c1.fp8 || (j == 0 && cfg.blocks <= 1)) return false;
+    return op_bwd_fusable_jg(dt(), geom(Bj.c2), N, Bj.Hin, Bj.Win, Bj.Hout, Bj.Wout, true, false, true) &&
+           op_bwd_fusable_jg(dt(), geom(Bj.cs), N, Bj.Hin, Bj.Win, Bj.Hout, Bj.Wout, false, true, false);
+  };
+  bool g_masked = false;             // g[cur] is masked by the ReLU of the block about to run its backward
   for (int i = nd - 1; i >= 0; --i) {
     Block& B = dec[i];
+    const bool jg = g_masked;
+    g_masked = false;
     const long npo = (long)N * B.Hout * B.Wout, npi = (long)N * B.Hin * B.Win;
     // (blocks > 1: block 0 has an identity shortcut and reads the stem's materialised activation)
     const void* xin = i == 0 ? (cfg.blocks > 1 ? base + P.act0d : base + P.y0d) : base + dec[i - 1].out;
@@ -1041,7 +1054,9 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
         MM_TRY(side_fork(s));
         MM_TRY(launch_tail_wgrad_finalize(wscratch_, np, grads + tail.off, wgrad_stream(s)));
       }
-    } else
+    } else if (jg)
+      np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, nullptr, nullptr, base + B.y2, ysp, npo, B.C, part, s, nullptr, nullptr);
+    else
       np = launch_bn_bwd_reduce(dt(), base + P.g[cur], nullptr, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.y2, ysp, npo, B.C, part, s, ssc, ssh);
     MM_TRY(np);
     if (B.identity) MM_TRY(bn_backward_coefs(B.b2, params, grads, base, np, 2, 0, (double)npo, s));
@@ -1078,6 +1093,8 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       C1.A = bnf(B.b1, base, 4); C1.B = bnf(B.b1, base, 5); C1.C = bnf(B.b1, base, 6);
       C1.xin = xin; C1.pxs = xs; C1.pxb = xb; C1.w1u = base + plan_.packed + B.c1.packU * (long)esz();
       C1.gin = base + P.g[cur ^ 1]; C1.part = ws2; C1.nrows = (long)N * B.Hin;
+      C1.mask_out = jg_block(i - 1) ? 1 : 0;
+      g_masked = C1.mask_out != 0;
       const int nb1 = launch_conv1_bwd_stream(C1, s);
       MM_TRY(nb1);
       {   // conv1: Conv2d weight (out = 16, in = Cin): partial images [out][in]
@@ -1091,7 +1108,9 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
       continue;
     }
     if (store8 && i == nd - 1) { set_error("fp8 storage of the last up-block needs join_bwd_stream"); return MMVAE_ERR_UNSUPPORTED; }
-    if (from_tail)
+    if (jg) {
+      // (no apply pass: the two fused passes below evaluate dy2 / dys from g[cur], y2 / ys and the coefficients)
+    } else if (from_tail)
       MM_TRY(launch_tail_join_bwd_apply(dt(), d_raw, params + tail.off, cfg.out_ch, N, Sd, Sd, bnf(B.b2, base, 2), bnf(B.b2, base, 3), bnf(B.bs, base, 2),
                                         bnf(B.bs, base, 3), base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5), bnf(B.b2, base, 6), base + P.dy2[ds],
                                         base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6), base + P.dys[ds], s));
@@ -1121,11 +1140,14 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
         MM_TRY(run_wgrad(B.c2, N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), base + P.dy2[ds], B.Hout, B.Wout, nullptr,
                          nullptr, grads, wsm));
       if (!fuse_cs) MM_TRY(run_wgrad(B.cs, N, xin, B.Hin, B.Win, xs, xb, base + P.dys[ds], B.Hout, B.Wout, nullptr, nullptr, grads, wsm));
+      if (jg && !(fuse_c2 && fuse_cs)) { set_error("decoder_bwd: the join-gradient form needs both fused passes"); return MMVAE_ERR_UNSUPPORTED; }
       if (fuse_c2) {
         // ... and bn1's backward sums come out of the same pass (the data gradient is in registers, y1 is the pass's P operand)
-        const int rcf = op_run_bwd_fused(dt(), geom(B.c2), N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1, base + P.dy2[ds],
+        const JoinGrad j2{base + B.y2, bnf(B.b2, base, 4), bnf(B.b2, base, 5), bnf(B.b2, base, 6)};
+        const int rcf = op_run_bwd_fused(dt(), geom(B.c2), N, base + B.y1, B.Hin, B.Win, bnf(B.b1, base, 2), bnf(B.b1, base, 3), 1,
+                                         jg ? base + P.g[cur] : base + P.dy2[ds],
                                          B.Hout, B.Wout, base + plan_.packed + B.c2.packD * (long)esz(), base + P.da1, nullptr, nullptr,
-                                         grads + B.c2.off, s, wsc2, B.c2.wscale, B.C == 16 ? part : nullptr);
+                                         grads + B.c2.off, s, wsc2, B.c2.wscale, B.C == 16 ? part : nullptr, nullptr, 1.f, jg ? &j2 : nullptr);
         if (rcf <= 0) { if (rcf == 0) set_error("decoder_bwd: fused backward of %s not taken", "conv2"); return rcf < 0 ? rcf : MMVAE_ERR_UNSUPPORTED; }
         if (B.C == 16) np_b1 = rcf;
       } else
@@ -1145,10 +1167,11 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
     if (B.identity)     // d_xin already holds the shortcut's share: the 1x1 conv's data gradient is added to it
       MM_TRY(run_up(B.c1, base, N, base + P.dy1[ds], B.Hin, B.Win, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 1, s));
     else if (fuse_cs) {  // shortcut ConvT: weight gradient + data gradient + the 1x1 conv's share (dy1 (x) w1) and ITS weight gradient, one pass over dys
-      const int rcf = op_run_bwd_fused(dt(), geom(B.cs), N, xin, B.Hin, B.Win, xs, xb, 1, base + P.dys[ds], B.Hout, B.Wout,
+      const JoinGrad js{base + B.ys, bnf(B.bs, base, 4), bnf(B.bs, base, 5), bnf(B.bs, base, 6)};
+      const int rcf = op_run_bwd_fused(dt(), geom(B.cs), N, xin, B.Hin, B.Win, xs, xb, 1, jg ? base + P.g[cur] : base + P.dys[ds], B.Hout, B.Wout,
                                        base + plan_.packed + B.cs.packD * (long)esz(), base + P.g[cur ^ 1], base + P.dy1[ds],
                                        base + plan_.packed + B.c1.packU * (long)esz(), grads + B.cs.off, s,
-                                       reinterpret_cast<float*>(base + P.wscratch2), B.cs.wscale, nullptr, grads + B.c1.off, B.c1.wscale);
+                                       reinterpret_cast<float*>(base + P.wscratch2), B.cs.wscale, nullptr, grads + B.c1.off, B.c1.wscale, jg ? &js : nullptr);
       if (rcf <= 0) { if (rcf == 0) set_error("decoder_bwd: fused backward of %s not taken", "upsample"); return rcf < 0 ? rcf : MMVAE_ERR_UNSUPPORTED; }
     } else              // one kernel: the 1x1 conv's data gradient (dy1, already on this block's input grid) is a second source of the shortcut's
       MM_TRY(run_down(B.cs, base, N, base + P.dys[ds], B.Hout, B.Wout, base + P.g[cur ^ 1], B.Hin, B.Win, nullptr, nullptr, 0, nullptr, 0, dt(), s,
