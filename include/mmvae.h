@@ -126,6 +126,9 @@ MMVAE_API int mmvae_net_join(mmvae_net* net, void* stream);
  * (above).  Used by the host side to take the loss scalars of reference model.py:385-406 (KL, MMD, NLL sums: logged values that no
  * gradient kernel reads) off the critical stream of a train step. */
 MMVAE_API void* mmvae_net_fork(mmvae_net* net, void* stream);
+/* The side stream itself (NULL when the net runs on one stream), without a new ordering edge: for work that only depends on what the
+ * stream's earlier forks already ordered it behind (the host side enqueues the step's loss scalars there from the decoder's backward). */
+MMVAE_API void* mmvae_net_side_stream(mmvae_net* net);
 
 /* SyncBN: BatchNorm statistics over the global batch of a data-parallel job.  `fn` must SUM the `n` f32 values at
  * device pointer `buf` over all ranks in place, ordered on `stream` (the caller's stream or the net's side stream), and return 0;

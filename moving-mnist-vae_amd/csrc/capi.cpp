@@ -125,6 +125,8 @@ void* mmvae_net_fork(mmvae_net* n, void* stream) {
   return reinterpret_cast<void*>(n->net->fork(S(stream)));
 }
 
+void* mmvae_net_side_stream(mmvae_net* n) { return n ? reinterpret_cast<void*>(n->net->side()) : nullptr; }
+
 int mmvae_net_set_sync_bn(mmvae_net* n, mmvae_allreduce_fn fn, void* user, int world) {
   if (!n || (fn && world < 1)) { set_error("net_set_sync_bn: bad argument"); return MMVAE_ERR_ARG; }
   n->net->set_sync_bn(reinterpret_cast<mmvae::Net::AllReduceFn>(fn), user, world);

@@ -159,6 +159,7 @@ class Net {
   void set_sync_bn_comm(Comm* c, Comm* side = nullptr) { comm_ = c; comm_side_ = c ? side : nullptr; ar_fn_ = nullptr; ar_user_ = nullptr; ar_world_ = c ? comm_world(c) : 1; }
   bool sync_bn_on() const { return ar_fn_ != nullptr || comm_ != nullptr; }
   int join(hipStream_t s) { return side_join(s); }
+  hipStream_t side() const { return side_state_ == 1 ? side_ : nullptr; }                       // nullptr: one stream
   hipStream_t fork(hipStream_t s) { return side_fork(s) == MMVAE_OK ? wgrad_stream(s) : s; }   // the side stream, ordered behind s
  private:
   int bn_train(const Bn& bn, const float* params, float* bnbuf, long long* nbt, char* base, int nparts, double count, hipStream_t s, long part_off = 0,

@@ -146,6 +146,17 @@ class _DecoderFn(torch.autograd.Function):
             torch.autograd.Variable._execution_engine.queue_callback(lambda: check(lib().mmvae_net_join(h, st), "mmvae_net_join"))
         if model._sync is not None:
             model._sync.bucket_ready(G, model._dec_off, model._n_params, side_of=model if defer else None)
+        pend = model.__dict__.get("_pending_loss")
+        if pend is not None:
+            # the step's loss scalars (_LossFn.forward): behind the decoder's weight gradients on the side stream -- every fork of this pass
+            # ordered that stream behind the forward pass already, so no new wait is needed, and the stream idles here until the encoder's
+            # weight gradients arrive
+            model.__dict__["_pending_loss"] = None
+            side = lib().mmvae_net_side_stream(model._h)
+            pend[0](side if side else _stream())
+            if side and not defer:
+                h, st = model._h, _stream()
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: check(lib().mmvae_net_join(h, st), "mmvae_net_join"))
         return (None, d_enc) + model._grad_views(G, 1)
 
 
@@ -279,39 +290,52 @@ class _LossFn(torch.autograd.Function):
         dev = recon.device
         acc = torch.zeros(4, dtype=torch.float64, device=dev)      # px, kl, mmd
         out = torch.empty(4, dtype=torch.float32, device=dev)      # loss, px/N, kl/N, mmd/N
-        st = _stream()
         # `model._loss_side` (set by VAE.loss(deferred=True) inside a train step): the loss scalars are logged values -- no gradient kernel
-        # reads them -- so their kernels (KL, MMD, NLL / CE sums, the combine) run on the net's side stream beside the backward pass that the
-        # host enqueues next; the stream is ordered before the caller's again by the backward pass's own join (mmvae_encoder_bwd /
-        # mmvae_net_join) or by the first read of the scalars (_StepScalars.ready).  Every operand stays alive in ctx until then.
+        # reads them -- so their kernels (KL, MMD, NLL / CE sums, the combine) leave the critical stream: they are enqueued on the net's side
+        # stream by the decoder's backward pass, behind its weight gradients, where that stream idles while the caller's runs the latency-bound
+        # kernels around the latent code (_DecoderFn.backward); the backward pass's own join (mmvae_encoder_bwd / the end-of-backward
+        # mmvae_net_join) orders them before the caller's stream again.  Never launched by then (no decoder backward in the graph): the first
+        # read of the scalars, or the next loss, launches them on the caller's stream (VAE._flush_pending_loss).
         side = bool(model.__dict__.get("_loss_side")) and model._h is not None
         model.__dict__["_loss_side"] = False
-        if side:
-            st = L.mmvae_net_fork(model._h, st)
+        model._flush_pending_loss()
         base = acc.data_ptr()
         recon = recon.contiguous()
         categorical = model.pixelcnn is not None or model.decoder_out_channels > model.in_channels      # model.py:398
         if mu is not None and logvar is not None:
             mu, logvar = mu.contiguous(), logvar.contiguous()
-            check(L.mmvae_kl_fwd(ptr(mu), ptr(logvar), mu.numel(), base + 8, st), "mmvae_kl_fwd")
+        scratch = None
         if encoding is not None:
             encoding = encoding.contiguous()
             scratch = torch.empty(2 * N, dtype=torch.float32, device=dev)
-            check(L.mmvae_mmd_fwd(ptr(true_samples), ptr(encoding), N, encoding.shape[1], ptr(scratch), base + 16, st), "mmvae_mmd_fwd")
-            ctx.keep = (scratch, acc)
-        if categorical:
-            target = target.contiguous()
-            Q, HW = recon.shape[1], recon.shape[2] * recon.shape[3]
-            check(L.mmvae_ce_fwd(ptr(recon), ptr(target), ptr(weight), N, Q, HW, base, st), "mmvae_ce_fwd")
+        target = target.contiguous()
+        nll_c, kl_c, mmd_c, sigma = float(model.nll), float(model.kl), float(model.mmd), float(model.sigma_decoder)
+        # the closure keeps every operand alive until it is dropped (VAE._loss_keep) -- as detached views: a tensor with a grad_fn would keep
+        # the step's autograd graph, whose nodes hold the model, in a reference cycle with it (45 GB workspaces waiting for the cycle collector)
+        det = lambda t: None if t is None else t.detach()
+        k_mu, k_lv, k_enc, k_rec, k_tgt, k_ts, k_w = det(mu), det(logvar), det(encoding), det(recon), det(target), det(true_samples), det(weight)
+
+        def launch(st):
+            if k_mu is not None and k_lv is not None:
+                check(L.mmvae_kl_fwd(ptr(k_mu), ptr(k_lv), k_mu.numel(), base + 8, st), "mmvae_kl_fwd")
+            if k_enc is not None:
+                check(L.mmvae_mmd_fwd(ptr(k_ts), ptr(k_enc), N, k_enc.shape[1], ptr(scratch), base + 16, st), "mmvae_mmd_fwd")
+            if categorical:
+                Q, HW = k_rec.shape[1], k_rec.shape[2] * k_rec.shape[3]
+                check(L.mmvae_ce_fwd(ptr(k_rec), ptr(k_tgt), ptr(k_w), N, Q, HW, base, st), "mmvae_ce_fwd")
+            else:
+                check(L.mmvae_gauss_nll_fwd(ptr(k_rec), ptr(k_tgt), k_rec.numel(), sigma, base, st), "mmvae_gauss_nll_fwd")
+            check(L.mmvae_loss_finish(base, ptr(out), nll_c, kl_c, mmd_c, float(N), st), "mmvae_loss_finish")
+            _ = acc                     # (referenced: the accumulator lives as long as the closure)
+
+        if side:
+            model.__dict__["_pending_loss"] = (launch, out)
         else:
-            target = target.contiguous()
-            check(L.mmvae_gauss_nll_fwd(ptr(recon), ptr(target), recon.numel(), float(model.sigma_decoder), base, st), "mmvae_gauss_nll_fwd")
-        check(L.mmvae_loss_finish(base, ptr(out), float(model.nll), float(model.kl), float(model.mmd), float(N), st), "mmvae_loss_finish")
+            launch(_stream())
+        model.__dict__["_loss_keep"] = launch
         model._last_scalars = out
         model.__dict__["_last_on_side"] = side
         ctx.model, ctx.N, ctx.categorical = model, N, categorical
-        if side and not hasattr(ctx, "keep"):
-            ctx.keep = (acc,)
         # the reconstruction is the decoder's own output tensor (no crop, no copy): its gradient can be folded into the decoder's backward
         lr = model._last_recon
         ctx.direct_tail = (lr[1] if (lr is not None and lr[0] == recon.data_ptr() and not categorical and model.fuse_loss_tail and
@@ -762,6 +786,13 @@ class VAE(nn.Module):
         check(lib().mmvae_mmd_fwd(ptr(x), ptr(y), x.shape[0], x.shape[1], None, ptr(acc), _stream()), "mmvae_mmd_fwd")
         return acc[0].float()
 
+    def _flush_pending_loss(self, only=None):
+        """Launch loss-scalar kernels still waiting for a decoder backward pass (_LossFn.forward) on the current stream."""
+        pend = self.__dict__.get("_pending_loss")
+        if pend is not None and (only is None or pend[1] is only):
+            self.__dict__["_pending_loss"] = None
+            pend[0](_stream())
+
     def loss(self, target, encoding_mu, encoding_logvar, encoding, reconstruction, device, args, deferred=False):
         """model.py:385-406: returns (loss tensor with grad, nll/N, kl/N, mmd/N as Python floats) -- ONE device->host
         copy of the four scalars instead of the reference's three ``.item()`` calls.  ``deferred=True`` (used by this
@@ -790,8 +821,13 @@ class VAE(nn.Module):
         loss_t = _LossFn.apply(self, target, encoding_mu, encoding_logvar, enc2, reconstruction, ts, weight)
         join = None
         if self.__dict__.get("_last_on_side"):
-            net = self                          # (keeps the net alive until the scalars have been read)
-            join = lambda: check(lib().mmvae_net_join(net._h, _stream()), "mmvae_net_join")
+            wr, mine = weakref.ref(self), self._last_scalars    # (weak: the group hangs off the model)
+
+            def join():
+                net = wr()
+                if net is not None and net._h is not None:     # (a destroyed net has synchronised its side stream)
+                    net._flush_pending_loss(mine)
+                    check(lib().mmvae_net_join(net._h, _stream()), "mmvae_net_join")
         grp = _StepScalars(self._last_scalars, join)
         self._last_group = grp
         if deferred:

@@ -393,3 +393,65 @@ def test_deferred_side_join_decoder_only_backward():
         bad = {n: (float((a - b).abs().max()), float(b.abs().max())) for n, a, b in zip(names, got, ref) if not torch.equal(a, b)}
         assert not bad, bad
     assert any(float(g.abs().max()) > 0 for g in ref)
+
+
+def test_loss_scalars_off_the_critical_stream_and_no_reference_cycle():
+    """train() takes the step's loss scalars (KL, MMD, NLL sums, reference model.py:385-406) off the caller's stream: the decoder's backward
+    enqueues them on the net's side stream (VAE.loss(deferred=True), _LossFn.forward).  (1) The values are the ones the in-stream form
+    returns, to the bit (same kernels, same inputs), for every step of a short run; (2) scalars whose backward never ran are still
+    computed when read; (3) the bookkeeping holds no reference cycle with the model -- `del model` frees it (and its multi-GB workspace)
+    without the cycle collector."""
+    import gc
+    import types
+    import weakref
+    M = _M()
+    pkg = importlib.import_module("moving-mnist-vae_amd")
+    dev = torch.device("cuda")
+    args = types.SimpleNamespace(data_ratio_of_labels=None, dataset="MovingMNIST", quiet=True)
+    g = torch.Generator().manual_seed(5)
+    batches = [(torch.rand((2, 20, 64, 64), generator=g) < 0.05).long() for _ in range(3)]
+
+    def run(deferred):
+        torch.manual_seed(11)
+        m = M.VAE(1, 32, 1, 2, 32, False, False, 4, "ReLu", 1, 1, 1, True, 0.1, 64, compute_dtype="bf16").to(dev).train()
+        opt = M.FusedAdam(list(m.parameters()))
+        if deferred:
+            out = pkg.train(m, batches, opt, dev, args, data_mean=0.05, data_std=0.22)
+            vals = [[float(v) for v in col] for col in out]
+        else:
+            vals = [[], [], [], []]
+            for b in batches:
+                image, target = pkg.main.prepare_batch(m, b, dev, args, 0.05, 0.22)
+                mu, lv, enc, rec = m(image)
+                loss, nll, kl, mmd = m.loss(target, mu, lv, enc, rec, dev, args)          # in-stream form, Python floats
+                for col, v in zip(vals, (loss.item(), nll, kl, mmd)):
+                    col.append(float(v))
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+        return m, opt, vals
+
+    # (the first optimizer a process constructs stays referenced by frames torch keeps from its lazy torch._dynamo import: not ours to test)
+    warm = M.VAE(1, 32, 1, 2, 32, False, False, 4, "ReLu", 1, 1, 1, True, 0.1, 64, compute_dtype="bf16").to(dev)
+    M.FusedAdam(list(warm.parameters()))
+    del warm
+    gc.collect()
+    gc.disable()
+    try:
+        m1, o1, side_vals = run(True)
+        m2, o2, main_vals = run(False)
+        assert side_vals == main_vals, (side_vals, main_vals)
+        # (2) a loss whose backward never runs: the first read launches the kernels
+        image, target = pkg.main.prepare_batch(m1, batches[0], dev, args, 0.05, 0.22)
+        mu, lv, enc, rec = m1(image)
+        loss, nll, kl, mmd = m1.loss(target, mu, lv, enc, rec, dev, args, deferred=True)
+        assert m1.__dict__.get("_pending_loss") is not None
+        v = float(nll)
+        assert m1.__dict__.get("_pending_loss") is None and v == v and v > 0
+        del loss, nll, kl, mmd, mu, lv, enc, rec, image, target
+        # (3) no cycle
+        refs = [weakref.ref(m1), weakref.ref(m2)]
+        del m1, o1, m2, o2
+        assert all(r() is None for r in refs), "the model survives `del`: a reference cycle keeps it (and its workspace) alive"
+    finally:
+        gc.enable()
