@@ -83,6 +83,19 @@ int op_deep2_up_ok(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_ph
   for (int i = 0; i < np; ++i) { if (ph[i].ntaps == 0 && !allow_empty_phases) return 0; ntaps += ph[i].ntaps; }
   return deep2_shape_ok(dt, g.D0, g.D1, (Hl + g.s - 1) / g.s, (Wl + g.s - 1) / g.s, Hs, Ws, ntaps, fp8) ? 1 : 0;
 }
+// whether the bf16 position-major kernel (conv_pos.inc) takes this layer's FORWARD launch -- the conditions of try_pos (conv_gemm.hip).  The
+// fp8 mode keeps such a layer in bf16: pos_conv_kernel at bf16 beats the e4m3 form of deep2_conv_kernel on these shapes (round 4).
+bool op_pos_fwd_takes(const ConvGeom& g, int Hl, bool transposed) {
+  const int Hs = conv_down_size(Hl, g.k, g.s, g.p);
+  const int Hi = transposed ? Hs : Hl, Ho = transposed ? Hl : Hs;
+  const int Cin = transposed ? g.D0 : g.D1, Cout = transposed ? g.D1 : g.D0;
+  if (Cout % 32 != 0 || Cin % 8 != 0 || (Hi >= 8 && Cout < 128)) return false;
+  if (transposed && g.s > 1 && g.k < g.s) return false;
+  const int nw = Cout / 32 < 8 ? Cout / 32 : 8;
+  if ((Cout / 32) % nw != 0 || (64 * nw) % (Cin / 8) != 0) return false;
+  return pos_conv_takes(g.k, g.s, g.p, transposed ? 1 : 0, Hi, Ho, Cin);
+}
+
 int op_frag_down(int dt, const ConvGeom& g, int Hl, int Wl, int fp8) { return frag_enabled() ? op_deep2_down_ok(dt, g, Hl, Wl, fp8) : 0; }
 int op_frag_up(int dt, const ConvGeom& g, int Hl, int Wl, int allow_empty_phases, int fp8) {
   return frag_enabled() ? op_deep2_up_ok(dt, g, Hl, Wl, allow_empty_phases, fp8) : 0;

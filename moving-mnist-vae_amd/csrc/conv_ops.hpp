@@ -50,6 +50,7 @@ int op_run_wgrad_pair(int dt, const ConvGeom& g, const ConvGeom& gs, int N, cons
 // Taken: returns the number of rows (> 0).  scratch: kWgradScratchBytes, not shared with a concurrent wgrad.
 // dW2 (optional, with x2): the weight gradient of the 1x1 conv itself, [16][D0] row-major (Conv2d (out, in, 1, 1)) += scale2 * x2^T (x) pro(P):
 // both rows are in LDS for the pass anyway.
+bool op_pos_fwd_takes(const ConvGeom& g, int Hl, bool transposed);   // the bf16 position-major kernel takes the layer's forward launch
 bool op_bwd_fusable(int dt, const ConvGeom& g, int N, int Hs, int Ws, int Hl, int Wl);
 int op_run_bwd_fused(int dt, const ConvGeom& g, int N, const void* P, int Hs, int Ws, const float* proP_s, const float* proP_b, int proP_relu,
                      const void* G, int Hl, int Wl, const void* packed_down, void* dP, const void* x2, const void* w2_packed, float* dW,

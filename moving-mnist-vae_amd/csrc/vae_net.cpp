@@ -45,9 +45,11 @@ ConvW Net::add_conv(const std::string& name, int D0, int D1, int k, int s, int p
 
 // An fp8 layer's forward weights are e4m3 bytes that only the fp8 form of deep2_conv_kernel reads: keep the flag only where that kernel
 // takes the layer's FORWARD launch (e.g. z = 192 makes decoder.conv1 a 3-chunk row, which it does not) -- the others stay bf16 layers.
+// So do the layers on 2x2 / 4x4 maps whose forward the bf16 position-major kernel takes: it is faster there than the e4m3 deep2 form (with them
+// in fp8 the mode ran at 0.96x of bf16 in round 4) -- fp8 arithmetic stays where it pays.
 void Net::settle_fp8(ConvW& w) const {
   if (!w.fp8) return;
-  const bool ok = w.Hl > 0 && (w.tr ? op_deep2_up_ok(DT_BF16, ConvGeom{w.D0, w.D1, w.k, w.s, w.p}, w.Hl, w.Hl, 1, 1)
+  const bool ok = w.Hl > 0 && !op_pos_fwd_takes(ConvGeom{w.D0, w.D1, w.k, w.s, w.p}, w.Hl, w.tr) && (w.tr ? op_deep2_up_ok(DT_BF16, ConvGeom{w.D0, w.D1, w.k, w.s, w.p}, w.Hl, w.Hl, 1, 1)
                                     : op_deep2_down_ok(DT_BF16, ConvGeom{w.D0, w.D1, w.k, w.s, w.p}, w.Hl, w.Hl, 1));
   if (!ok) { w.fp8 = false; w.wscale = 1.f; }
 }
