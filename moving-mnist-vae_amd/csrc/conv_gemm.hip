@@ -255,6 +255,8 @@ int conv_xcd_walk() {
   return 1;      // XCD-aware tile order (measured neutral to slightly positive; the switch is gone)
 }
 
+// (round 4, all sixteen channel-heavy layers through gather_gemm_kernel again for reference: 1.1-5.7x slower than the kernel each runs on
+// today, forward and data gradient, except uplayer3.conv1's forward -- 19.6 vs 24.1 us; the switch stays a constant)
 bool conv_force_v1() {
   constexpr int v = 0;
   return v != 0;
@@ -424,6 +426,8 @@ bool deep2_shape_ok(int dt, int Cin, int Cout, int Hq, int Wq, int Hi, int Wi, i
   if (Cin < (fp8 ? 64 : 32) || (Cin * ES) % 64 != 0 || (cpt != c0 && cpt != 2 * c0 && cpt != 4 * c0 && cpt != 8 * c0)) return false;   // Cin 32, 64, 128, 256
   if (Cout < 32 || Cout % 32 != 0 || (Cout > 256 && Cout % 256 != 0)) return false;
   if (Cin < 64 && Cout < 64) return false;          // the 16/32-channel layers are the patch-tile kernel's (weights resident in LDS)
+  // (32 -> 32 with 16 taps -- decoder.uplayer3.conv2, whose weights + patch do not fit the patch-tile kernel's LDS -- measured here in round 4:
+  // forward 84 us against patch_conv's 90, data gradient 84 us against the first-generation gather_gemm's 45: left where it was)
   const int hw = Hq * Wq;
   if (hw < 1 || hw > 128 || Hq > 255 || Wq > 255 || ntaps_all < 1 || ntaps_all > kMaxTaps) return false;
   const int npt_min = hw > 64 ? 8 : hw > 32 ? 4 : 2;
@@ -779,9 +783,17 @@ static int try_wgrad2(int dt, const WgradArgs& a, hipStream_t s) {
   if (a.P_planar && (a.Ca != 16 || a.P_planes > 16 || a.proP_scale)) return 0;
   if (a.G_planar && (a.Cb != 16 || a.Ca != 32 || a.proG_scale || a.ntaps < 4)) return 0;
   auto pick = [](int c) { return c >= 64 ? 64 : c; };
-  const int TA = pick(a.Ca), TB = pick(a.Cb);
+  int TA = pick(a.Ca), TB = pick(a.Cb);
   if (!(TA == 16 || TA == 32 || TA == 64) || !(TB == 16 || TB == 32 || TB == 64)) return 0;
   if (a.Ca % TA || a.Cb % TB) return 0;
+  // a 1x1 stride-2 layer on 4x4 maps (encoder.layer3's shortcut): the 128-pixel tile's G patch is 8 images x 7x7 pixels, 50 KB at 64
+  // channels -- it fits with a 32-channel G tile (the k-split mode cannot shrink the pixel tile instead)
+  if (a.ntaps < 4 && TB == 64 && !a.P_planar && !a.G_planar) {
+    Wgrad2Args probe; memset(&probe, 0, sizeof(probe));
+    probe.TG = wgrad2_taps_per_block(TA / 16, 4, a.ntaps); probe.nw = 4;
+    if (make_tile_geom(probe.g, a.N, a.Hp, a.Wp, a.Hg, a.Wg, a.stride, -a.pad, -a.pad, a.ksz, a.ksz, 128, 1) &&
+        (wgrad2_lds_bytes(probe, dt, TA, 64) > kV2MaxLds || wgrad2_patch_slots(probe, dt, 64) > 16)) TB = 32;
+  }
   const int ta16 = TA / 16, tb16 = TB / 16;
   Wgrad2Args b; memset(&b, 0, sizeof(b));
   b.P = a.P; b.G = a.G; b.dW = a.dW;
