@@ -45,11 +45,11 @@ def pick(step):
     jb = [k for k, n in enumerate(names) if "join_bwd_stream_kernel" in n]
     ta = [k for k, n in enumerate(names) if "tail_apply_mfma_kernel" in n]
     tb = [k for k, n in enumerate(names) if "tail_join_bwd_kernel" in n]
-    # the wgrad2 family (bench.py's weight-gradient table): the step issues its 11 wgrad2 launches in a fixed order that starts with
+    # the wgrad2 family (bench.py's weight-gradient table): the step issues its 12 wgrad2 launches in a fixed order that starts with
     # decoder.uplayer3 (conv2, upsample, conv1) and ends with encoder.layer2 (conv2, downsample, conv1) -- the candidates for the family's
     # slowest instance are the first two and the last three.  Each launch's partial-image reduce is the next wgrad_reduce dispatch.
     w2 = [k for k, n in enumerate(names) if "wgrad2_kernel" in n]
-    if len(w2) == 11:
+    if len(w2) in (11, 12):     # (12 since encoder.layer3's 1x1 stride-2 shortcut runs on it too)
         for idx, layer in ((0, "decoder.uplayer3.0.conv2"), (1, "decoder.uplayer3.0.upsample.0"), (-3, "encoder.layer2.0.conv2"),
                            (-2, "encoder.layer2.0.downsample.0"), (-1, "encoder.layer2.0.conv1")):
             k = w2[idx]
