@@ -129,6 +129,11 @@ MMVAE_API void* mmvae_net_fork(mmvae_net* net, void* stream);
 /* The side stream itself (NULL when the net runs on one stream), without a new ordering edge: for work that only depends on what the
  * stream's earlier forks already ordered it behind (the host side enqueues the step's loss scalars there from the decoder's backward). */
 MMVAE_API void* mmvae_net_side_stream(mmvae_net* net);
+/* Backward form of the up-blocks on 16-wide maps (decoder.uplayer4; reference model.py:70-85 autograd).  1 (default): the block above hands
+ * its input gradient down already masked by this block's join ReLU, the join BatchNorms' backward reduce runs unmasked and dy is evaluated
+ * by the loaders of the two fused ConvTranspose2d backward passes -- no apply pass, no dy tensors.  0: reduce -> apply -> consumers, the form
+ * every other block uses.  Same arithmetic per element; the parity tests compare the two. */
+MMVAE_API int mmvae_net_set_join_grad(mmvae_net* net, int enable);
 
 /* SyncBN: BatchNorm statistics over the global batch of a data-parallel job.  `fn` must SUM the `n` f32 values at
  * device pointer `buf` over all ranks in place, ordered on `stream` (the caller's stream or the net's side stream), and return 0;

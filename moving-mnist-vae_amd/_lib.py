@@ -38,6 +38,7 @@ PROTOTYPES = {
     "mmvae_net_join": (c_int, [P, P]),
     "mmvae_net_fork": (P, [P, P]),
     "mmvae_net_side_stream": (P, [P]),
+    "mmvae_net_set_join_grad": (c_int, [P, c_int]),
     "mmvae_net_set_sync_bn": (c_int, [P, P, P, c_int]),
     "mmvae_rsample_fwd": (c_int, [P, P, P, P, c_int64, P]),
     "mmvae_rsample_bwd": (c_int, [P, P, P, P, P, c_int64, P]),

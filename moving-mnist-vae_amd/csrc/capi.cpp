@@ -125,6 +125,12 @@ void* mmvae_net_fork(mmvae_net* n, void* stream) {
   return reinterpret_cast<void*>(n->net->fork(S(stream)));
 }
 
+int mmvae_net_set_join_grad(mmvae_net* n, int enable) {
+  if (!n) { set_error("net_set_join_grad: bad argument"); return MMVAE_ERR_ARG; }
+  n->net->set_join_grad(enable != 0);
+  return MMVAE_OK;
+}
+
 void* mmvae_net_side_stream(mmvae_net* n) { return n ? reinterpret_cast<void*>(n->net->side()) : nullptr; }
 
 int mmvae_net_set_sync_bn(mmvae_net* n, mmvae_allreduce_fn fn, void* user, int world) {

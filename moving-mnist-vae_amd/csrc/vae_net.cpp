@@ -1025,7 +1025,7 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   // by this block's join ReLU (conv1_bwd_stream_kernel, MASK), the BatchNorm-backward reduce runs unmasked, and dy2 / dys are evaluated by the
   // loaders of the two fused ConvTranspose2d backward passes -- the bn_bwd_apply launch (840 MB at N = 5120) and both dy tensors disappear.
   auto jg_block = [&](int j) {
-    if (j < 0 || j >= nd || dt() != DT_BF16) return false;
+    if (j < 0 || j >= nd || dt() != DT_BF16 || !join_grad_) return false;
     const Block& Bj = dec[j];
     if (Bj.identity || Bj.C != 16 || Bj.c2.fp8 || Bj.cs.fp8 || Bj.c1.fp8 || (j == 0 && cfg.blocks <= 1)) return false;
     return op_bwd_fusable_jg(dt(), geom(Bj.c2), N, Bj.Hin, Bj.Win, Bj.Hout, Bj.Wout, true, false, true) &&

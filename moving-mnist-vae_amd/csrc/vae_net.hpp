@@ -151,6 +151,10 @@ class Net {
   int sync_rows(char* base, const float* partials, int nparts, int width, hipStream_t s, float** out, int row_stride = 0);
  public:
   void set_defer_join(bool v) { defer_join_ = v; }
+  // the join-gradient form of a 16-wide block's backward (decoder_bwd: masked gradient handed down, dy evaluated by the consumers' loaders);
+  // off = the reduce -> apply -> consumers form every other block uses (kept reachable for the A/B parity test)
+  bool join_grad_ = true;
+  void set_join_grad(bool v) { join_grad_ = v; }
   // SyncBN: fn sums a device f32 buffer over all ranks, ordered on the given stream; NULL = per-rank statistics
   typedef int (*AllReduceFn)(float* buf, long long n, void* stream, void* user);
   void set_sync_bn(AllReduceFn fn, void* user, int world) { ar_fn_ = fn; ar_user_ = user; ar_world_ = fn ? world : 1; comm_ = comm_side_ = nullptr; }
