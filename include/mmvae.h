@@ -324,6 +324,12 @@ MMVAE_API int mmvae_upblock_tail_fwd(const void* y1, const float* s1, const floa
                                      const float* bx, const float* wu, const float* s2, const float* b2, const float* ss, const float* bs,
                                      const float* tail_weight, const float* tail_bias, float* r_raw, float* stats, int N, void* scratch,
                                      void* stream);
+/* A block's residual join fused with the NEXT block's conv1 (reference model.py:86-88 of block i, :72 of block i + 1; conv_joinfwd.hip; bf16):
+ *   out = relu(s2 y2 + b2 + ss ys + bs)  [npix][C]  (C = 16 or 32; written: the upsample branch and the backward pass read it),
+ *   y1 = conv1(out), w_conv1 (16, C, 1, 1) f32, no bias, [npix][16];  stats (nullable): <return value> partial rows [2][16] = (sum, sum of
+ *   squares) of y1 from the f32 accumulators.  npix a multiple of 32; scratch >= 2 KB (the packed weight). */
+MMVAE_API int mmvae_join_conv1x1_fwd(const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs,
+                           const float* w_conv1, int C, void* out, void* y1, float* stats, int64_t npix, void* scratch, void* stream);
 MMVAE_API int mmvae_conv1x1_bwd_fused(const void* d_a1, const void* y1, const float* s1, const float* b1, const float* A1, const float* B1,
                             const float* C1, const void* xin, const float* sx, const float* bx, const float* w_conv1, float* dw_conv1,
                             void* g_in, int64_t rows, void* scratch, void* stream);

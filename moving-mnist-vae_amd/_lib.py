@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mmvae_tail_join_bwd_reduce": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_tail_join_bwd_apply": (c_int, [c_int, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "mmvae_upblock_bwd_fused": (c_int, [P] * 27 + [c_int, P, P]),
+    "mmvae_join_conv1x1_fwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, c_int64, P, P]),
     "mmvae_conv1x1_bwd_fused": (c_int, [P] * 13 + [c_int64, P, P]),
     "mmvae_upblock_tail_fwd": (c_int, [P] * 16 + [c_int, P, P]),
     "mmvae_pixelcnn_create": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int]),

@@ -507,6 +507,14 @@ int mmvae_conv1x1_bwd_fused(const void* da1, const void* y1, const float* s1, co
   u.part = C.part; u.dW = dw1; u.Ca = 16; u.Cb = 16; u.ntaps = 1; u.nparts = nb; u.Ca_valid = 16; u.Cb_valid = 16; u.sA = 16; u.sB = 1; u.scale = 1.f;
   return launch_wgrad_reduce(u, S(st));
 }
+int mmvae_join_conv1x1_fwd(const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs, const float* w1, int C,
+                           void* out, void* y1, float* stats, int64_t npix, void* scratch, void* st) {
+  if (!y2 || !s2 || !b2 || !ys || !ss || !bs || !w1 || !out || !y1 || !scratch) { set_error("join_conv1x1_fwd: bad argument"); return MMVAE_ERR_ARG; }
+  if (!join_conv1_fwd_ok(DT_BF16, C, 16, (long)npix)) { set_error("join_conv1x1_fwd: C=%d npix=%ld unsupported (16 / 32 channels, whole 32-pixel steps)", C, (long)npix); return MMVAE_ERR_UNSUPPORTED; }
+  const ConvGeom g = geom_for(0, C, 16, 1, 1, 0);
+  const int rc = op_pack_down(DT_BF16, g, w1, scratch, S(st)); if (rc < 0) return rc;
+  return launch_join_conv1_fwd(C, y2, s2, b2, ys, ss, bs, scratch, out, y1, stats, (long)npix, S(st));
+}
 int mmvae_convert(int di, int dout, const void* in, void* out, int64_t n, void* st) { return launch_convert(di, dout, in, out, (long)n, S(st)); }
 
 }  // extern "C"

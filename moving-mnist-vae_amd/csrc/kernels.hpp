@@ -104,6 +104,10 @@ struct Conv1BwdLaunch {
   int mask_out = 0;   // g_in leaves masked by the ReLU that produced xin (xin > 0): the block below evaluates its BatchNorm backward on load (JoinGrad)
 };
 int launch_conv1_bwd_stream(const Conv1BwdLaunch& L, hipStream_t s);  // returns blocks
+// conv_joinfwd.hip: a block's residual join fused with the next block's 1x1 conv1 (16 outputs) and bn1's statistics; C = joined channels (16 / 32)
+bool join_conv1_fwd_ok(int dt, int C, int Cout_next, long npix);
+int launch_join_conv1_fwd(int C, const void* y2, const float* s2, const float* b2, const void* ys, const float* ss, const float* bs, const void* w1_down,
+                          void* out, void* y1, float* stats, long npix, hipStream_t s);   // returns the rows of `stats`
 
 // ---------------------------------------------------------------- v2 patch-tile kernels (conv_tile.hip)
 // A tile is up to TP (128, or 64/32 for wgrad on tiny feature maps) q-pixels: `qr` consecutive q-rows of one image (tiles_per_img > 0) or `segs` whole images.

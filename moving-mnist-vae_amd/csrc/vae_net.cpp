@@ -880,6 +880,7 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     MM_TRY(launch_affine_act(dt(), base + P.y0d, xs, xb, 1, base + P.act0d, (long)N * 4, 128, s));
     xin = base + P.act0d; xs = xb = nullptr;
   }
+  int c1_done = 0;                 // rows of bn1 statistics the previous block's join kernel left for this block's conv1 (0: conv1 not done)
   for (int i = 0; i < nd; ++i) {
     Block& B = dec[i];
     const double cnt = (double)N * B.Hout * B.Wout;
@@ -897,7 +898,9 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
       MM_TRY(np);
       MM_TRY(training ? bn_train(B.bs, params, bnbuf, nbt, base, np, cnt, ss, kPartialFloats, B.cs.wscale) : bn_eval(B.bs, params, bnbuf, base, ss, B.cs.wscale));
     }
-    np = run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hin, B.Win, xs, xb, 1, stats, 0, dt(), s);
+    // (conv1 already done: the previous block's join kernel computed it from the joined row it had in LDS -- join_conv1_fwd below)
+    np = c1_done > 0 ? c1_done : run_down(B.c1, base, N, xin, B.Hin, B.Win, base + B.y1, B.Hin, B.Win, xs, xb, 1, stats, 0, dt(), s);
+    c1_done = 0;
     MM_TRY(np);
     MM_TRY(training ? bn_train(B.b1, params, bnbuf, nbt, base, np, (double)N * B.Hin * B.Win, s, 0, B.c1.wscale) : bn_eval(B.b1, params, bnbuf, base, s, B.c1.wscale));
     if (B.identity)    // 3x3 Conv2d, shape preserving
@@ -913,6 +916,17 @@ int Net::decoder_fwd(int N, const float* encv, const float* params, float* bnbuf
     if (fork) MM_TRY(side_join(s));
     if (i == nd - 1 && tail_fwd_fused()) break;     // the join of the last block happens inside the tail conv kernel
     if (i == nd - 1 && store8) { set_error("fp8 storage of the last up-block needs the fused tail kernels (MMVAE_TAIL_FWD_FUSED / MMVAE_TAIL_FUSED)"); return MMVAE_ERR_UNSUPPORTED; }
+    // the join, fused with the next block's 1x1 conv1 and bn1's statistics where that block's conv1 is 16-wide (uplayer3 -> 4, uplayer4 -> 5):
+    // the joined row is the conv's operand while it is in LDS -- one launch and one pass over `out` fewer than join -> conv
+    const bool fuse_c1 = i + 1 < nd && !B.identity && !dec[i + 1].identity && !dec[i + 1].c1.fp8 && dec[i + 1].c1.k == 1 && dec[i + 1].c1.s == 1 &&
+                         dec[i + 1].c1.D1 == B.C && frag_down(dec[i + 1].c1) == 0 && dec[i + 1].c1.wscale == 1.f &&
+                         join_conv1_fwd_ok(dt(), B.C, dec[i + 1].c1.D0, (long)N * B.Hout * B.Wout);
+    if (fuse_c1) {
+      c1_done = launch_join_conv1_fwd(B.C, base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), base + B.ys, bnf(B.bs, base, 2), bnf(B.bs, base, 3),
+                                      base + plan_.packed + dec[i + 1].c1.packD * (long)esz(), base + B.out, base + dec[i + 1].y1, stats,
+                                      (long)N * B.Hout * B.Wout, s);
+      MM_TRY(c1_done);
+    } else
     MM_TRY(launch_join_fwd(dt(), base + B.y2, bnf(B.b2, base, 2), bnf(B.b2, base, 3), B.identity ? xin : base + B.ys,
                            B.identity ? ones(base) : bnf(B.bs, base, 2), B.identity ? zeros(base) : bnf(B.bs, base, 3), base + B.out,
                            (long)N * B.Hout * B.Wout, B.C, s));

@@ -307,3 +307,51 @@ def test_upblock_tail_forward_recomputed(N, pro_x):
     sums = stats[:rows].sum(0).cpu()
     assert abs(sums[0].item() - got.double().sum().item()) <= 1e-3 * got.double().abs().sum().item()
     assert abs(sums[1].item() - (got.double() ** 2).sum().item()) <= 1e-4 * (got.double() ** 2).sum().item()
+
+
+@pytest.mark.parametrize("C,N,H", [(16, 3, 32), (16, 70, 32), (32, 5, 16), (32, 257, 16), (16, 2, 64)])
+@pytest.mark.parametrize("with_stats", [True, False])
+def test_join_fused_with_the_next_blocks_conv1(C, N, H, with_stats):
+    """mmvae_join_conv1x1_fwd (conv_joinfwd.hip): a DeconvBottleneck's residual join (reference model.py:86-88) fused with the next block's
+    conv1 (1x1, C -> 16, no bias; model.py:72) and bn1's batch statistics, against torch CPU fp32 of the unfused graph on the same bf16 inputs
+    and bf16-rounded weights.  `out` is a bf16 rounding of an f32 value (2^-8 of its scale); y1 is a bf16 rounding of a C-term f32 sum of
+    bf16 products of the ROUNDED out (the kernel multiplies what it stores), so it is compared with the reference conv of the kernel's own
+    `out` (2^-8) and, loosely, of the reference `out`; the statistics come from the f32 accumulators: 2e-3 of their scale.  Ragged N: the
+    last steps belong to fewer waves than the grid has."""
+    L = _lib()
+    lib = L.lib()
+    torch.manual_seed(C * 1000 + N)
+    y2 = torch.randn(N, H, H, C).to(torch.bfloat16)
+    ys = torch.randn(N, H, H, C).to(torch.bfloat16)
+    s2, ss = torch.rand(C) + 0.5, torch.rand(C) + 0.5
+    b2, bs = torch.randn(C) * 0.3, torch.randn(C) * 0.3
+    w = torch.randn(16, C) * 0.2
+    ref_out = torch.relu(y2.float() * s2 + b2 + ys.float() * ss + bs)
+    wr = w.to(torch.bfloat16).float()
+    d = torch.device("cuda")
+    g = lambda t: t.contiguous().to(d)
+    y2d, ysd, s2d, b2d, ssd, bsd, wd = g(y2), g(ys), g(s2), g(b2), g(ss), g(bs), g(w.view(16, C, 1, 1))
+    out = torch.empty(N, H, H, C, device=d, dtype=torch.bfloat16)
+    y1 = torch.empty(N, H, H, 16, device=d, dtype=torch.bfloat16)
+    stats = torch.full((1024 * 32,), float("nan"), device=d)
+    scratch = torch.empty(4096, dtype=torch.uint8, device=d)
+    st = torch.cuda.current_stream().cuda_stream
+    rows = lib.mmvae_join_conv1x1_fwd(L.ptr(y2d), L.ptr(s2d), L.ptr(b2d), L.ptr(ysd), L.ptr(ssd), L.ptr(bsd), L.ptr(wd), C, L.ptr(out), L.ptr(y1),
+                                      L.ptr(stats) if with_stats else None, N * H * H, L.ptr(scratch), st)
+    L.check(rows, "mmvae_join_conv1x1_fwd")
+    torch.cuda.synchronize()
+    got_out, got_y1 = out.float().cpu(), y1.float().cpu()
+    scale_o = float(ref_out.abs().max())
+    assert float((got_out - ref_out).abs().max()) <= 2.0 ** -8 * scale_o + 1e-6
+    ref_y1_own = got_out @ wr.t()                        # the conv of what the kernel stored
+    scale_y = float(ref_y1_own.abs().max())
+    assert float((got_y1 - ref_y1_own).abs().max()) <= 2.0 ** -8 * scale_y + 1e-5
+    assert float((got_y1 - ref_out @ wr.t()).abs().max()) <= 2.0 ** -6 * scale_y
+    if with_stats:
+        assert 0 < rows <= 1024
+        part = stats[:rows * 32].view(rows, 2, 16).double().sum(0).cpu()
+        assert torch.isfinite(part).all()
+        ref = ref_y1_own.double().view(-1, 16)
+        s_ref, q_ref = ref.sum(0), (ref * ref).sum(0)
+        assert float((part[0] - s_ref).abs().max()) <= 2e-3 * float(ref.abs().sum(0).max())
+        assert float((part[1] - q_ref).abs().max()) <= 2e-3 * float(q_ref.max())
