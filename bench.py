@@ -328,17 +328,60 @@ def convt4_family_roofline(M, device, N, reps=20):
             "in_step": in_step, "family_in_step": fam, "family_layers_isolated": rows}
 
 
+def wgrad_stream_family_roofline(M, device, N, reps=10):
+    """The wgrad_stream_kernel family (weight gradients of the big thin layers as per-wave streams: uplayer4's two fused backward passes on the
+    caller's stream, encoder.layer1's conv2 and conv1 + shortcut pair on the side stream): its largest instance, the pair -- both weight gradients
+    of encoder.layer1's 3x3 stride-2 conv1 and 1x1 stride-2 shortcut from ONE pass over the 32x32x32 block input -- timed in isolation through the
+    C ABI (mmvae_conv2d_wgrad_pair: the kernel + its two ordered reduces).  Algorithmic bytes = x + dy + dy_shortcut (bf16), once."""
+    L = importlib.import_module(PKG + "._lib")
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    wsc = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    x = torch.randn(N, 32, 32, 32, device=device).to(torch.bfloat16)
+    dy = torch.randn(N, 16, 16, 32, device=device).to(torch.bfloat16)
+    dys = torch.randn(N, 16, 16, 32, device=device).to(torch.bfloat16)
+    dw, dws = torch.zeros(32, 32, 3, 3, device=device), torch.zeros(32, 32, 1, 1, device=device)
+    sc, sh = torch.rand(32, device=device) + 0.5, torch.randn(32, device=device) * 0.1
+
+    def fn():
+        L.check(lib.mmvae_conv2d_wgrad_pair(1, L.ptr(x), L.ptr(dy), L.ptr(dys), L.ptr(dw), L.ptr(dws), N, 32, 32, 32, 32, L.ptr(sc), L.ptr(sh), 1,
+                                            L.ptr(wsc), st), "conv2d_wgrad_pair")
+    ms = _time_calls(fn, reps, warm=2)
+    alg = (x.numel() + dy.numel() + dys.numel()) * 2
+    ach = alg / (ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic("wgrad_stream.encoder.layer1.pair", N)
+    top = committed_top_kernels(N)
+    fam = None if top is None else next((f for f in top["families"] if f["family"] == "wgrad_stream_kernel"), None)
+    in_step = None
+    if top is not None:
+        me = next((l for l in top.get("largest", []) if "wgrad_stream_kernel<3, 2" in l["kernel"]), None)
+        if me is not None:
+            in_step = {"ms": me["ms"], "GBs": round(alg / (me["ms"] * 1e-3) / 1e9, 1), "frac": round(alg / (me["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                       "measured_hbm_MB": me.get("hbm_MB"), "stream": me.get("stream"), "source": top["source"],
+                       "note": "the last launch of the step's side stream: it runs beside stem_bwd_kernel, which reads the same block input"}
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+            "kernel": "wgrad_stream_kernel<3x3 s2 + centre-tap companion> (+ 2 wgrad_reduce_kernel) @ encoder.layer1.conv1 + downsample.0: both weight gradients from one "
+                      "read of the block input (per-wave strips, G-row ring + P rows in wave-private LDS, 10 tap accumulators x 2x2 channel tiles in registers, "
+                      "per-block partial images, ordered reduce): the largest instance of the step's largest kernel family by GPU time.  `achieved` / `frac`: "
+                      "isolated mmvae_conv2d_wgrad_pair calls timed here; `in_step`: the same launch in the committed trace",
+            "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms, "achieved_GBs": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBS,
+            "in_step": in_step, "family_in_step": fam}
+
+
 def dominant_kernel_roofline(M, device, N, reps=10):
     """`roofline`: the kernel family with the most GPU time per step in the committed kernel statistics (profiles/*_top_kernels.json, taken on
     THIS build by tools/profile_round.sh) decides which kernel is reported: its largest instance, timed live in isolation.  Round 4: the weight
     gradients of the channel-heavy layers left wgrad2_kernel for wgrad_pos_kernel one by one, so the family that led rounds 2-3 may no longer
-    lead; the streaming ConvTranspose2d forward is the runner-up.  The weight-gradient table is kept beside it (`wgrad_families`)."""
+    lead; four families are within 8 % of each other now (wgrad_stream, deep2_conv, convT4_stream, pos_conv: 0.61-0.66 ms per step), and which of
+    them leads a given profile is decided by tens of microseconds.  The weight-gradient table is kept beside it (`wgrad_families`)."""
     top = committed_top_kernels(N)
     fams = [] if top is None else [f for f in top["families"] if f.get("ms")]
     dominant = fams[0]["family"] if fams else "wgrad2_kernel"
     w2 = wgrad2_family_roofline(M, device, N, reps)
     if "convT4_stream" in dominant:
         out = convt4_family_roofline(M, device, N)
+    elif "wgrad_stream" in dominant:
+        out = wgrad_stream_family_roofline(M, device, N)
     else:
         out = dict(w2)
         if "wgrad2" not in dominant:

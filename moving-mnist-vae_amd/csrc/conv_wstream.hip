@@ -119,10 +119,18 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { psc[j] = a.proP_scale[c + j]; psh[j] = a.proP_shift[c + j]; }
   }
-  if constexpr (PRO_G) {
+  // (G_TAB, the centre-tap companion form: G's prologue coefficients live in an LDS table behind the rings, read where a row is committed -- 16
+  // registers fewer across the loop: with them the form spilled 8 registers at the 256 limit)
+  constexpr bool G_TAB = PRO_G && P2;
+  float* gtab = reinterpret_cast<float*>(smem + WDB + NW * WAVE_LDS + (JG ? 3 * CB * 4 : 0));
+  if constexpr (PRO_G && !G_TAB) {
     const int c = (lane % (CBB / 16)) * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gsc[j] = a.proG_scale[c + j]; gsh[j] = a.proG_shift[c + j]; }
+  }
+  if constexpr (G_TAB) {
+    if (t < CB) { gtab[t] = a.proG_scale[t]; gtab[CB + t] = a.proG_shift[t]; }
+    __syncthreads();
   }
   // (JG) the coefficient table [3][CB] sits behind the rings in LDS and is read where a row is committed: 24 registers live for a few
   // instructions instead of the whole loop (the 32-channel second-source form is at the 256-register limit)
@@ -192,7 +200,31 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
   const int nq = a.HS / RP + 1;                             // steps of a unit: the priming step + one per RP P rows
 
   // registers of the step in flight
-  Vec16 gv[GV], jv[JG ? GV : 1], pv[PV], pv2[P2 ? PV : 1], xv = Vec16{{0, 0, 0, 0}};
+  // (the P / P2 / x2 rows in flight are native vectors: as `Vec16` -- a struct around an array -- rows that are only copied, not unpacked, stayed
+  // in scratch memory in every form without a P prologue: global load, wait, scratch store, scratch reload, LDS store -- no prefetch, 32-80 bytes
+  // of scratch per lane and step)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  Vec16 gv[GV], jv[JG ? GV : 1];
+  u32x4 pv[PV], pv2[P2 ? PV : 1], xv = (u32x4){0, 0, 0, 0};
+  // LATE_P (the centre-tap companion form: 40 accumulator fragments; the 32-channel second-source form): the next step's P rows are requested AFTER
+  // the step's MFMA section, not before it -- live across that section they do not fit 256 registers and the compiler parked them in scratch memory (load, wait, store to
+  // scratch, reload: no prefetch at all and 94 MB of scratch write-backs per launch in the round-4 profile)
+  constexpr bool LATE_P = P2 || (X2 && CA16 > 1);
+  auto issueP = [&](int u, int q) {
+    // (no branch: on the priming step, q = 0, the strip's first rows are loaded and dropped -- with the loads under `if (q > 0)` the arrays
+    // stayed in scratch memory in every 3x3 form: load, wait, scratch store, reload)
+    const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
+    const int hrow = h0 + RP * (q > 0 ? q - 1 : 0);
+#pragma unroll
+    for (int k = 0; k < PV; ++k)
+      pv[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(Pm) + (((long)n * a.Hp + hrow) * WP) * CAB + (lane + 64 * k) * 16);
+    if constexpr (X2) xv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.x2) + (((long)n * a.Hp + hrow) * WP) * 32 + lane * 16);
+    if constexpr (P2) {
+#pragma unroll
+      for (int k = 0; k < PV; ++k)
+        pv2[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a.P2) + (((long)n * a.Hp + hrow) * WP) * CAB + (lane + 64 * k) * 16);
+    }
+  };
   auto issue = [&](int u, int q) {
     const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
     const int hrow = h0 + RP * (q - 1);                     // first P row of the step (q = 0: the rows above the strip's first step)
@@ -210,17 +242,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
         if constexpr (JG) jv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.Jy) + (((long)n * a.Hg + row) * Wg) * CBB + off);
       }
     }
-    if (q > 0) {
-#pragma unroll
-      for (int k = 0; k < PV; ++k)
-        pv[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(Pm) + (((long)n * a.Hp + hrow) * WP) * CAB + (lane + 64 * k) * 16);
-      if constexpr (X2) xv = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.x2) + (((long)n * a.Hp + hrow) * WP) * 32 + lane * 16);
-      if constexpr (P2) {
-#pragma unroll
-        for (int k = 0; k < PV; ++k)
-          pv2[k] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const char*>(a.P2) + (((long)n * a.Hp + hrow) * WP) * CAB + (lane + 64 * k) * 16);
-      }
-    }
+    if constexpr (!LATE_P) issueP(u, q);
   };
   auto commit = [&](int u, int q) {
     const int n = u / nstrips, h0 = (u - n * nstrips) * a.HS;
@@ -235,8 +257,20 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
         if constexpr (PRO_G) if (row >= 0 && row < a.Hg) {
           float f[8];
           Elem<bf16_t>::unpack(v, f);
+          if constexpr (G_TAB) {
+            const int c = (lane % (CBB / 16)) * 8;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * gsc[j] + gsh[j], g_lo);
+            for (int h = 0; h < 2; ++h) {
+              const float4 cs = *reinterpret_cast<const float4*>(gtab + c + 4 * h), cb = *reinterpret_cast<const float4*>(gtab + CB + c + 4 * h);
+              f[4 * h + 0] = fmaxf(f[4 * h + 0] * cs.x + cb.x, g_lo);
+              f[4 * h + 1] = fmaxf(f[4 * h + 1] * cs.y + cb.y, g_lo);
+              f[4 * h + 2] = fmaxf(f[4 * h + 2] * cs.z + cb.z, g_lo);
+              f[4 * h + 3] = fmaxf(f[4 * h + 3] * cs.w + cb.w, g_lo);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * gsc[j] + gsh[j], g_lo);
+          }
           v = Elem<bf16_t>::pack(f);
         }
         if constexpr (JG) if (row >= 0 && row < a.Hg) {        // (rows outside the map stay zero: they are the conv's padding)
@@ -262,21 +296,21 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
     if (q > 0) {
 #pragma unroll
       for (int k = 0; k < PV; ++k) {
-        Vec16 v = pv[k];
-        if constexpr (ST) *reinterpret_cast<Vec16*>(rawrow + (lane + 64 * k) * 16) = v;
+        u32x4 v = pv[k];
+        if constexpr (ST) *reinterpret_cast<u32x4*>(rawrow + (lane + 64 * k) * 16) = v;
         if constexpr (PRO_P) {
           float f[8];
-          Elem<bf16_t>::unpack(v, f);
+          Elem<bf16_t>::unpack(__builtin_bit_cast(Vec16, v), f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] * psc[j] + psh[j], p_lo);
-          v = Elem<bf16_t>::pack(f);
+          v = __builtin_bit_cast(u32x4, Elem<bf16_t>::pack(f));
         }
-        *reinterpret_cast<Vec16*>(prow + (lane + 64 * k) * 16) = v;
+        *reinterpret_cast<u32x4*>(prow + (lane + 64 * k) * 16) = v;
       }
-      if constexpr (X2) *reinterpret_cast<Vec16*>(x2row + lane * 16) = xv;
+      if constexpr (X2) *reinterpret_cast<u32x4*>(x2row + lane * 16) = xv;
       if constexpr (P2) {
 #pragma unroll
-        for (int k = 0; k < PV; ++k) *reinterpret_cast<Vec16*>(prow2 + (lane + 64 * k) * 16) = pv2[k];
+        for (int k = 0; k < PV; ++k) *reinterpret_cast<u32x4*>(prow2 + (lane + 64 * k) * 16) = pv2[k];
       }
     }
   };
@@ -399,6 +433,7 @@ __global__ __launch_bounds__(64 * NW, 2) void wgrad_stream_kernel(WStreamArgs a)
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LATE_P) { if (un < u_end) issueP(un, qn); }
     u = un; q = qn;
   }
 
@@ -468,7 +503,7 @@ static int launch_wstream_t(const WStreamArgs& a, int gx, hipStream_t s) {
   constexpr int WL = S * (WP - 1) + KS;
   constexpr int NSLOT = S * (RP - 1) + KS + S * RP;
   constexpr size_t rings = NW * (size_t)(NSLOT * WL * CB16 * 32 + 32 * CA16 * 32 + (X2 ? 32 * 32 : 0) + (ST ? 32 * CA16 * 32 : 0) + (P2 ? 32 * CA16 * 32 : 0)) +
-                           ((DG && CA16 > 1) ? CA16 * (KS * KS / 2) * 1024 : 0) + (JG ? 3 * CB16 * 16 * 4 : 0);
+                           ((DG && CA16 > 1) ? CA16 * (KS * KS / 2) * 1024 : 0) + (JG ? 3 * CB16 * 16 * 4 : 0) + ((PRO_G && P2) ? 2 * CB16 * 16 * 4 : 0);
   constexpr size_t flush = ((size_t)KS * KS * CA16 * 16 * CB16 * 16 + (X2 ? 16 * CA16 * 16 : 0) + (P2 ? CA16 * 16 * CB16 * 16 : 0)) * 4 + 512;
   constexpr size_t lds = rings > flush ? rings : flush;
   static_assert(lds <= 160 * 1024, "one block must fit the CU's LDS");

@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256, DG ? 3 : sizeof(T) == 2 ? 4 : 2) void stem_bwd
 
   // ---- software pipeline of this wave: registers of the NEXT slab
   Vec16 gv[NS], yv[NS], xv[NXV];
-  Vec16 dv[2];                                      // DG: the two dy rows of the next slab (16 pixels x 32 channels = one vector per lane)
+  // DG: the two dy rows of the next slab (16 pixels x 32 channels = one vector per lane).  Native vectors: as `Vec16` (a struct around an array)
+  // these copy-only rows stayed in scratch memory (32 bytes per lane: load, wait, scratch store, reload -- no prefetch)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 dv[2];
   int r0_c = 0, ph_n = 0;
   auto issue = [&](int slab) {
     const int n = slab / a.slabs_per_img, h0 = (slab - n * a.slabs_per_img) * a.rps;
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(256, DG ? 3 : sizeof(T) == 2 ? 4 : 2) void stem_bwd
       const int hq = h0 >> 1, Hs = a.Ho >> 1;
       ph_n = h0 & 1;
       const long rb = ((long)n * Hs + hq) * (long)(a.Wo >> 1) * 32 + lane * VE;
-      dv[0] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(a.dy1) + rb);
-      dv[1] = Vec16{{0, 0, 0, 0}};
-      if (!ph_n) dv[1] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(a.dys) + rb);
-      else if (hq + 1 < Hs) dv[1] = *reinterpret_cast<const Vec16*>(reinterpret_cast<const T*>(a.dy1) + rb + (long)(a.Wo >> 1) * 32);
+      dv[0] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.dy1) + rb);
+      dv[1] = (u32x4){0, 0, 0, 0};
+      if (!ph_n) dv[1] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.dys) + rb);
+      else if (hq + 1 < Hs) dv[1] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(a.dy1) + rb + (long)(a.Wo >> 1) * 32);
       const long base = (((long)n * a.Ho + h0) * a.Wo) * 32 + lane * VE;
 #pragma unroll
       for (int k = 0; k < NS; ++k) yv[k] = *reinterpret_cast<const Vec16*>(Y + base + k * 64 * VE);
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(256, DG ? 3 : sizeof(T) == 2 ? 4 : 2) void stem_bwd
   auto commit = [&]() {
     if constexpr (DG) {
       // ---- g slab = data gradient of conv1 (+ shortcut) for this output row, on the matrix cores: D[ci][pixel wq of column phase pw]
-      *reinterpret_cast<Vec16*>(sDy + (lane >> 2) * kDyPitch + (lane & 3) * 16) = dv[0];
-      *reinterpret_cast<Vec16*>(sDy + kDyRow + (lane >> 2) * kDyPitch + (lane & 3) * 16) = dv[1];
+      *reinterpret_cast<u32x4*>(sDy + (lane >> 2) * kDyPitch + (lane & 3) * 16) = dv[0];
+      *reinterpret_cast<u32x4*>(sDy + kDyRow + (lane >> 2) * kDyPitch + (lane & 3) * 16) = dv[1];
       const char* b0 = sDy + r * kDyPitch + gq * 16;               // B fragment: pixel r (+ dw), channels (co) 8 gq ..
       const Vec16 r0d0 = *reinterpret_cast<const Vec16*>(b0), r0d1 = *reinterpret_cast<const Vec16*>(b0 + kDyPitch);
       const Vec16 r1d0 = *reinterpret_cast<const Vec16*>(b0 + kDyRow), r1d1 = *reinterpret_cast<const Vec16*>(b0 + kDyRow + kDyPitch);

@@ -8,6 +8,7 @@ keys: uplayer5.conv2.fwd   the last convT4_stream_kernel (else patch_conv_kernel
       uplayer5.join_bwd   the last up-block's backward in one pass (join_bwd_stream_kernel); builds without it:
       uplayer5.join_bwd_apply = the apply pass of the join backward (tail_apply_mfma_kernel, else the second tail_join_bwd_kernel dispatch)
       wgrad2.<layer>   a wgrad2_kernel dispatch + its wgrad_reduce_kernel, for the five layers named in pick()
+      wgrad_stream.encoder.layer1.pair   the last wgrad_stream_kernel dispatch of the step + its two reduces
       __step__   every dispatch of the last train step (between two Adam kernels)
 usage: python tools/pmc_hbm_csv.py <fetch counter_collection.csv> <write counter_collection.csv> <frames> > profiles/rNN_pmc_hbm.csv"""
 import csv
@@ -55,6 +56,13 @@ def pick(step):
             k = w2[idx]
             red = next((q for q in range(k + 1, len(names)) if "wgrad_reduce_kernel" in names[q]), None)
             out["wgrad2." + layer] = step[k][1] + (step[red][1] if red is not None else 0.0)
+    # the wgrad_stream family's largest instance: encoder.layer1's conv1 + shortcut pair, the last wgrad_stream_kernel dispatch of the step
+    # (+ the two wgrad_reduce dispatches that follow it)
+    ws = [k for k, n in enumerate(names) if "wgrad_stream_kernel" in n]
+    if ws:
+        k = ws[-1]
+        reds = [q for q in range(k + 1, len(names)) if "wgrad_reduce_kernel" in names[q]][:2]
+        out["wgrad_stream.encoder.layer1.pair"] = step[k][1] + sum(step[q][1] for q in reds)
     if jb:
         out["uplayer5.join_bwd"] = step[jb[0]][1]
     elif ta or len(tb) > 1:
