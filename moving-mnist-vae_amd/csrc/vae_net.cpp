@@ -571,6 +571,7 @@ int Net::encoder_fwd(int N, const float* x, const float* params, float* bnbuf, l
   MM_TRY(packs_enc_fwd(params, base, s));
   MM_TRY(pack_batch_flush(dt(), s));
   eval_folded_ = false;
+  gram_ready_ = false; gram_fwd_N_ = training ? N : 0; gram_fwd_ws_ = ws;
   if (!training) MM_TRY(fold_bn_eval(0, params, bnbuf, base, s));
   if (!staged) MM_TRY(launch_convert(DT_F32, dt(), x, base + P.x_t, (long)N * cfg.in_ch * S * S, s));
   if (cfg.in_ch == 1 && stem_fwd_stream_ok(dt(), S)) {
@@ -686,12 +687,13 @@ int Net::encoder_bwd(int N, const float* d_mu, const float* d_logvar, const floa
     MM_TRY(launch_wgrad(dt(), a, wgrad_stream(s)));
     // the stem's im2col depends on the input image only: early, off the tail of the critical path
     // the stem's input-only work (patch gram matrix / im2col) early, off the tail of the critical path
-    if (stem_bwd_fused()) {
+    if (stem_bwd_fused() && !(gram_ready_ && gram_fwd_N_ == N && gram_fwd_ws_ == ws)) {
       MM_TRY(launch_stem_gram(dt(), base + P.x_t, reinterpret_cast<float*>(base + P.stem_gram), 1024L * stem_bwd_part_floats(),
                               reinterpret_cast<double*>(base + P.stem_R), N, cfg.S, H1, W1, wgrad_stream(s)));
       // the stem's finalize at the very end waits for THIS, not for the whole side stream (whose last weight gradients may still run)
       if (side_state_ == 1 && hipEventRecord(gram_ev_, side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
     }
+    gram_ready_ = false;            // (consumed: the next backward pass belongs to another forward pass)
     if (!stem_bwd_fused() && cfg.in_ch == 1 && stem_im2col_path() && wgrad_stream(s) != s) MM_TRY(launch_stem_im2col(dt(), base + P.x_t, base + P.col, N, cfg.S, cfg.S, H1, W1, wgrad_stream(s)));
     PackArgs pa; std::memset(&pa, 0, sizeof(pa));
     pa.src = params + head_mu.off; pa.dst = base + P.packed + head_pack_dg * (long)esz();
@@ -987,6 +989,17 @@ int Net::decoder_bwd(int N, const float* d_recon, const float* params, float* gr
   pack_batch_begin();
   MM_TRY(packs_dec_bwd(params, base, d_enc != nullptr, s));
   MM_TRY(pack_batch_flush(dt(), s));
+  // the encoder stem's patch gram matrix (input only; stem_bwd.hip): here the side stream is idle for ~1 ms beside HBM-bound kernels, at the
+  // start of encoder_bwd it ran beside the latency-bound kernels around the latent code and held their small launches up (lesson 55)
+  if (stem_bwd_fused() && !gram_ready_ && gram_fwd_N_ == N && gram_fwd_ws_ == ws && wgrad_stream(s) != s) {
+    MM_TRY(side_fork(s));
+    MM_TRY(launch_stem_gram(dt(), base + P.x_t, reinterpret_cast<float*>(base + P.stem_gram), 1024L * stem_bwd_part_floats(),
+                            reinterpret_cast<double*>(base + P.stem_R), N, cfg.S, H1, W1, wgrad_stream(s)));
+    if (hipEventRecord(gram_ev_, side_) != hipSuccess) { set_error("side stream mark failed"); return MMVAE_ERR_HIP; }
+    gram_ready_ = true;
+    // (the encoder backward's weight packs enqueued here as well -- 26 us off the caller's stream at the latent boundary -- change nothing:
+    // 6.018 vs 6.018 ms over three A/B pairs; not kept)
+  }
   // ---- output BN backward, tail conv backward
   int np = gauss ? launch_gauss_tail_reduce(r_raw, gauss->target, bnf(bn_out, base, 2), bnf(bn_out, base, 3), gauss->sigma, gauss->coef, gauss->gscale, N,
                                             cfg.out_ch, HW, part, s)

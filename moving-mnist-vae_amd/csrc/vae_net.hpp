@@ -110,6 +110,9 @@ class Net {
   int side_fork(hipStream_t s);                 // side stream waits for everything enqueued on s so far
   int side_join(hipStream_t s);                 // s waits for everything enqueued on the side stream so far
   hipEvent_t gram_ev_ = nullptr;                 // the stem's patch gram matrix is ready (side stream)
+  // the gram matrix depends on the staged input only: decoder_bwd launches it at ITS start, where the side stream idles beside the last
+  // up-block's HBM-bound backward, when the encoder forward it belongs to ran on this workspace (encoder_bwd launches it otherwise)
+  bool gram_ready_ = false; int gram_fwd_N_ = 0; const void* gram_fwd_ws_ = nullptr;
   hipEvent_t blk_ev_[16] = {};                   // side-stream progress marks, one per block of a backward pass
   int side_mark(int slot);                      // record mark `slot` on the side stream
   int side_wait_mark(int slot, hipStream_t s);  // s waits for mark `slot`
