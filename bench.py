@@ -368,6 +368,65 @@ def wgrad_stream_family_roofline(M, device, N, reps=10):
             "in_step": in_step, "family_in_step": fam}
 
 
+# the layers whose forward / data-gradient launches run on pos_conv_kernel (maps up to 4x4, >= 128 output channels or 4x4 inputs) and on
+# deep2_conv_kernel (the 64-channel layers on 8x8 / 16x16 maps): name, transposed, Cin, Cout, k, stride, pad, H (input side of the forward op)
+CONV_FAMILY_LAYERS = {
+    "pos_conv_kernel": [("encoder.layer3.0.conv2", 0, 128, 128, 3, 1, 1, 4), ("encoder.layer4.0.conv1", 0, 128, 256, 3, 2, 1, 4),
+                        ("encoder.layer4.0.conv2", 0, 256, 256, 3, 1, 1, 2), ("decoder.uplayer1.0.conv2", 1, 128, 128, 4, 2, 1, 2),
+                        ("decoder.uplayer2.0.conv2", 1, 64, 64, 4, 2, 1, 4), ("decoder.uplayer2.0.upsample.0", 1, 128, 64, 4, 2, 1, 4)],
+    "deep2_conv_kernel": [("encoder.layer2.0.conv1", 0, 32, 64, 3, 2, 1, 16), ("encoder.layer2.0.conv2", 0, 64, 64, 3, 1, 1, 8),
+                          ("encoder.layer3.0.conv1", 0, 64, 128, 3, 2, 1, 8), ("decoder.uplayer3.0.upsample.0", 1, 64, 32, 4, 2, 1, 8)],
+}
+
+
+def conv_family_roofline(M, device, N, family, reps=10):
+    """The tile-kernel families of the channel-heavy forward / data-gradient convolutions (pos_conv_kernel, deep2_conv_kernel): every layer of the
+    family timed in isolation through the C ABI (mmvae_conv2d_fwd with the BatchNorm + ReLU prologue and statistics, mmvae_conv2d_dgrad), the
+    SLOWEST launch is the family's largest instance: algorithmic bytes = input + output activations (bf16) + weights, flops = 2 * pixels * Cin *
+    Cout * k^2 (nominal: what the layer is, padded taps included); bound = mfma when flops / bytes exceeds the bf16 ridge (2.5 PF / 8 TB/s)."""
+    L = importlib.import_module(PKG + "._lib")
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    rows = []
+    for name, tr, Cin, Cout, k, sd, p, H in CONV_FAMILY_LAYERS[family]:
+        Ho = (H - 1) * sd - 2 * p + k if tr else (H + 2 * p - k) // sd + 1
+        w = torch.randn((Cin, Cout, k, k) if tr else (Cout, Cin, k, k), device=device) * 0.05
+        x = torch.randn(N, H, H, Cin, device=device).to(torch.bfloat16)
+        y = torch.empty(N, Ho, Ho, Cout, device=device, dtype=torch.bfloat16)
+        dx = torch.empty_like(x)
+        scratch = torch.empty(4 * w.numel() + 1024, device=device, dtype=torch.uint8)
+        sc, sh = torch.rand(Cin, device=device) + 0.5, torch.randn(Cin, device=device) * 0.1
+        stats = torch.empty(4096 * 2 * Cout, device=device)
+
+        def fwd(pack=False):
+            L.check(lib.mmvae_conv2d_fwd(1, tr, L.ptr(x), L.ptr(w) if pack else None, L.ptr(y), N, H, H, Cin, Cout, k, sd, p, L.ptr(sc), L.ptr(sh), 1,
+                                         L.ptr(stats), L.ptr(scratch), st), name)
+
+        def dgrad():
+            L.check(lib.mmvae_conv2d_dgrad(1, tr, L.ptr(y), L.ptr(w), L.ptr(dx), N, H, H, Cin, Cout, k, sd, p, L.ptr(scratch), st), name)
+        fwd(True)
+        flop = 2.0 * N * (H * H if tr else Ho * Ho) * Cin * Cout * k * k
+        alg = (x.numel() + y.numel() + w.numel()) * 2
+        rows.append(dict(layer=name, op="forward", ms=_time_calls(fwd, 6, warm=1), flop=flop, bytes=alg))
+        rows.append(dict(layer=name, op="data gradient (+ its weight pack launch)", ms=_time_calls(dgrad, 6, warm=1), flop=flop, bytes=alg))
+        del x, y, dx
+    worst = max(rows, key=lambda r: r["ms"])
+    ms, alg, flop = worst["ms"], worst["bytes"], worst["flop"]
+    gbs, tfs = alg / (ms * 1e-3) / 1e9, flop / (ms * 1e-3) / 1e12
+    mfma_bound = flop / alg > MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    top = committed_top_kernels(N)
+    fam = None if top is None else next((f for f in top["families"] if f["family"] == family), None)
+    return {"bound": "mfma" if mfma_bound else "hbm", "achieved": tfs if mfma_bound else gbs, "peak": MFMA_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": (tfs / MFMA_PEAK_TFLOPS) if mfma_bound else (gbs / HBM_PEAK_GBS),
+            "traffic": None, "traffic_source": None,
+            "kernel": f"{family} @ {worst['layer']} {worst['op']}: the slowest isolated launch of the step's largest kernel family by GPU time in the committed "
+                      f"profile ({len(rows)} launches of {len(rows) // 2} layers timed through mmvae_conv2d_fwd / mmvae_conv2d_dgrad)",
+            "algorithmic_bytes_per_launch": alg, "algorithmic_flop_per_launch": flop, "avg_launch_ms": ms, "achieved_GBs": gbs, "achieved_TFLOPs": tfs,
+            "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "frac_of_mfma_peak": tfs / MFMA_PEAK_TFLOPS, "family_in_step": fam,
+            "family_launches_isolated": [{"layer": r["layer"], "op": r["op"], "ms": round(r["ms"], 4),
+                                          "frac_of_mfma_peak": round(r["flop"] / (r["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 3)} for r in rows]}
+
+
 def dominant_kernel_roofline(M, device, N, reps=10):
     """`roofline`: the kernel family with the most GPU time per step in the committed kernel statistics (profiles/*_top_kernels.json, taken on
     THIS build by tools/profile_round.sh) decides which kernel is reported: its largest instance, timed live in isolation.  Round 4: the weight
@@ -382,6 +441,8 @@ def dominant_kernel_roofline(M, device, N, reps=10):
         out = convt4_family_roofline(M, device, N)
     elif "wgrad_stream" in dominant:
         out = wgrad_stream_family_roofline(M, device, N)
+    elif dominant in CONV_FAMILY_LAYERS:
+        out = conv_family_roofline(M, device, N, dominant)
     else:
         out = dict(w2)
         if "wgrad2" not in dominant:
